@@ -1,0 +1,103 @@
+"""ctypes binding of libcswin_hip.so (C ABI: include/cswin_hip.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  `lib()` raises if the
+shared object is missing or does not export every symbol of the header, and every op raises if
+its tensors are not on a HIP device.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
+
+import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so the kernels share its HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcswin_hip.so")
+
+P, I, F, SZ, L, D = c_void_p, c_int, c_float, c_size_t, c_long, c_double
+
+# name -> (restype, argtypes); mirrors include/cswin_hip.h one to one (tests/test_abi.py checks both ways)
+SIGNATURES = {
+    "cswin_last_error": (c_char_p, []),
+    "cswin_abi_version": (I, []),
+    "cswin_device_ok": (I, []),
+    "cswin_attn_fwd": (I, [P, P, P, P, P, I, I, I, I, P, P, I, F, P]),
+    "cswin_attn_bwd_workspace": (SZ, [I, I, I, I, P, P, I]),
+    "cswin_attn_bwd": (I, [P, P, P, P, P, P, P, P, SZ, I, I, I, I, P, P, I, F, P]),
+    "cswin_img2windows": (I, [P, P, I, I, I, I, I, I, P]),
+    "cswin_windows2img": (I, [P, P, I, I, I, I, I, I, P]),
+    "cswin_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
+    "cswin_layernorm_bwd_workspace": (SZ, [I, I]),
+    "cswin_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, P]),
+    "cswin_linear_fwd": (I, [P, P, I, P, P, P, P, P, P, I, I, I, I, P]),
+    "cswin_linear_bwd_data": (I, [P, P, P, P, I, P, P, I, P, I, I, I, P]),
+    "cswin_linear_bwd_weight_workspace": (SZ, [I, I, I]),
+    "cswin_linear_bwd_weight": (I, [P, P, P, I, P, I, P, P, P, SZ, I, I, I, P]),
+    "cswin_conv_tok_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "cswin_conv_tok_bwd_data": (I, [P, P, P, I, I, I, I, I, I, I, I, P]),
+    "cswin_conv_tok_bwd_weight_workspace": (SZ, [I, I, I, I, I, I, I, I]),
+    "cswin_conv_tok_bwd_weight": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, I, I, P]),
+    "cswin_conv_weight_permute": (I, [P, P, P, I, I, I, I, P]),
+    "cswin_conv_weight_unpermute": (I, [P, P, I, I, I, I, P]),
+    "cswin_nchw_to_tokens": (I, [P, P, I, I, I, I, I, P]),
+    "cswin_tokens_to_nchw": (I, [P, P, I, I, I, I, I, P]),
+    "cswin_carafe_fwd": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "cswin_carafe_bwd_workspace": (SZ, [I, I, I, I, I]),
+    "cswin_carafe_bwd": (I, [P, P, P, P, P, P, P, SZ, I, I, I, I, I, P]),
+    "cswin_loss_workspace": (SZ, [I, I, L]),
+    "cswin_loss_sums": (I, [P, P, P, P, SZ, I, I, L, P]),
+    "cswin_loss_finalize": (I, [P, P, P, D, I, F, F, P]),
+    "cswin_loss_bwd": (I, [P, P, P, P, P, F, F, I, I, L, P]),
+    "cswin_sgd_flat": (I, [P, P, P, L, P, F, F, F, P]),
+    "cswin_multi_copy": (I, [P, I, P]),
+}
+
+_lib = None
+
+
+class CswinHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library (cached).  Raises CswinHipError if it is missing or incomplete."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CswinHipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                f"(or `make -C cswin_unet_amd/csrc`). There is no fallback path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise CswinHipError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise with cswin_last_error() on failure."""
+    h = lib()
+    rc = getattr(h, name)(*args)
+    if rc != 0:
+        raise CswinHipError(f"{name} failed ({rc}): {h.cswin_last_error().decode()}")
+
+
+def ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev_f32(t, what="tensor"):
+    """Validate a tensor for the HIP path: HIP device, fp32, contiguous (copies only if strided)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise CswinHipError(f"{what} is on {t.device}: the cswin_unet_amd ops run on a HIP device only (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise CswinHipError(f"{what} has dtype {t.dtype}; the HIP path computes in fp32")
+    return t if t.is_contiguous() else t.contiguous()

@@ -1,0 +1,624 @@
+// Fused cross-shaped-window attention (LePEAttention, networks/cswin_unet.py:31-109) for gfx950.
+//
+// One workgroup = one (branch, window, head).  Nothing of the reference's intermediate tensors
+// exists: q/k/v rows are gathered straight from the (B, L, 3C) output of the qkv Linear with the
+// stripe index map  l = (ih*H_sp + r)*W + iw*W_sp + c  (img2windows / im2cswin /
+// get_lepe never materialise), K/V stripes are staged in LDS, S = QK^T and PV run on
+// v_mfma_f32_16x16x4_f32 (exact fp32) with the KEY index on MFMA rows so that
+//   * softmax row statistics are per-lane reductions over registers + two cross-group shuffles,
+//   * the P tile in its accumulator layout is directly the B operand of the PV product
+//     (no LDS round trip for P),
+// the LePE 3x3 depthwise conv (zero padded at the WINDOW border) is evaluated from the V tile
+// already in LDS, and the epilogue scatters to (B, L, C) at the branch's channel offset
+// (windows2img + torch.cat fused).  Both branches of a block run in ONE launch.
+//
+// Backward recomputes S from q,k and the saved row log-sum-exp.  Each wave owns 16
+// keys: dK^T and dV^T accumulate in registers over all query tiles (P / dS accumulator tiles
+// are again direct MFMA B operands), delta = rowsum(P o dP) is reduced through LDS, dS crosses
+// LDS once for dQ, LePE^T(dO) is added to dV, and the depthwise-conv weight/bias gradients are
+// written as per-workgroup partial slabs (reduced deterministically by a second tiny kernel).
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 32;          // head dim (64/2 = 128/4 = 256/8 = 512/16)
+constexpr int LDT = HD + 4;     // LDS row stride of the [token][d] images
+
+struct AttnBranch {
+    int c0;          // first channel of this branch inside C
+    int heads;       // heads of this branch
+    int head0;       // global index of its first head (for the lse layout)
+    int H_sp, W_sp, nW, nWin;
+    int wg_begin;    // first workgroup of this branch
+    const float* lepe_w;   // [Cb][9]
+    const float* lepe_b;   // [Cb]
+    float* dw_part;        // backward: [wg_local][10][32] partial slabs (9 taps + bias)
+};
+
+struct AttnParams {
+    const float* qkv;      // (B, L, 3C)
+    float* y;              // (B, L, C)        forward output
+    float* lse;            // (B, heads_total, L)
+    const float* dy;       // (B, L, C)        backward input
+    float* dqkv;           // (B, L, 3C)       backward output
+    int B, reso, C, heads_total;
+    float scale;
+    int nbranch;
+    AttnBranch br[2];
+};
+
+struct WgInfo {
+    int bi, b, win, g, N, ih, iw;
+};
+
+__device__ __forceinline__ WgInfo decode_wg(const AttnParams& p, int wg) {
+    WgInfo w;
+    w.bi = (p.nbranch > 1 && wg >= p.br[1].wg_begin) ? 1 : 0;
+    const AttnBranch& br = p.br[w.bi];
+    int loc = wg - br.wg_begin;
+    w.g = loc % br.heads;
+    int t = loc / br.heads;
+    w.win = t % br.nWin;
+    w.b = t / br.nWin;
+    w.ih = w.win / br.nW;
+    w.iw = w.win - w.ih * br.nW;
+    w.N = br.H_sp * br.W_sp;
+    return w;
+}
+
+// in-window token t -> image token l
+__device__ __forceinline__ int token_of(const AttnBranch& br, const WgInfo& w, int reso, int t) {
+    int r = t / br.W_sp, c = t - r * br.W_sp;
+    return (w.ih * br.H_sp + r) * reso + w.iw * br.W_sp + c;
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// =====================================================================================
+// forward
+// =====================================================================================
+template <int NT>
+__global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnParams p) {
+    constexpr int NP = 16 * NT;
+    constexpr int NW = NT < 8 ? NT : 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                  // [NP][LDT]
+    float* Vs = Ks + NP * LDT;         // [NP][LDT]
+    float* Wl = Vs + NP * LDT;         // [10][32]: 9 taps + bias of this head's channels
+
+    const WgInfo w = decode_wg(p, blockIdx.x);
+    const AttnBranch& br = p.br[w.bi];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int L = p.reso * p.reso, C3 = 3 * p.C;
+    const int ch0 = br.c0 + w.g * HD;           // first channel of this head inside C
+    const int N = w.N;
+    const float* qkv_b = p.qkv + (long)w.b * L * C3;
+
+    for (int idx = tid; idx < NP * 8; idx += 64 * NW) {
+        const int row = idx >> 3, c4 = idx & 7;
+        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+        if (row < N) {
+            const float* src = qkv_b + (long)token_of(br, w, p.reso, row) * C3 + ch0 + 4 * c4;
+            kv = *reinterpret_cast<const f32x4*>(src + p.C);
+            vv = *reinterpret_cast<const f32x4*>(src + 2 * p.C);
+        }
+        *reinterpret_cast<f32x4*>(&Ks[row * LDT + 4 * c4]) = kv;
+        *reinterpret_cast<f32x4*>(&Vs[row * LDT + 4 * c4]) = vv;
+    }
+    for (int i = tid; i < 10 * HD; i += 64 * NW) {
+        const int tap = i / HD, ch = i - tap * HD;
+        const int cb = ch0 - br.c0 + ch;        // channel inside the branch
+        Wl[i] = tap < 9 ? br.lepe_w[cb * 9 + tap] : br.lepe_b[cb];
+    }
+    __syncthreads();
+
+    for (int qt = wave; qt < NT; qt += NW) {
+        const int tq = 16 * qt + li;
+        const bool qvalid = tq < N;
+        const int lq = qvalid ? token_of(br, w, p.reso, tq) : 0;
+        float qr[8];
+        {
+            f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;
+            if (qvalid) {
+                const float* src = qkv_b + (long)lq * C3 + ch0 + 8 * kq;
+                q0 = *reinterpret_cast<const f32x4*>(src);
+                q1 = *reinterpret_cast<const f32x4*>(src + 4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                qr[e] = q0[e] * p.scale;
+                qr[4 + e] = q1[e] * p.scale;
+            }
+        }
+        // S^T tiles: rows = keys (16 kt + 4 kq + reg), col = query li
+        f32x4 s[NT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const float* kp = &Ks[(16 * kt + li) * LDT + 8 * kq];
+            const f32x4 k0 = *reinterpret_cast<const f32x4*>(kp);
+            const f32x4 k1 = *reinterpret_cast<const f32x4*>(kp + 4);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma4(k0[e], qr[e], acc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma4(k1[e], qr[4 + e], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (16 * kt + 4 * kq + r >= N) acc[r] = -INFINITY;
+                mx = fmaxf(mx, acc[r]);
+            }
+            s[kt] = acc;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[kt][r] - mx);
+                s[kt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+
+        // O^T[d][q] = sum_key V[key][d] * P^T[key][q]; the P accumulator tile is the B operand as it stands
+        f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* vp = &Vs[(16 * kt + 4 * kq + r) * LDT + li];
+                o[0] = mfma4(vp[0], s[kt][r], o[0]);
+                o[1] = mfma4(vp[16], s[kt][r], o[1]);
+            }
+        // lane now holds O^T[d = 16 df + 4 kq + e][q = li]
+        if (qvalid) {
+            const int rr = tq / br.W_sp, cc = tq - rr * br.W_sp;
+#pragma unroll
+            for (int df = 0; df < 2; ++df) {
+                const int d0 = 16 * df + 4 * kq;
+                f32x4 acc = *reinterpret_cast<const f32x4*>(&Wl[9 * HD + d0]);     // bias
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int r2 = rr + ky - 1, c2 = cc + kx - 1;
+                        if ((unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp) {
+                            const f32x4 wv = *reinterpret_cast<const f32x4*>(&Wl[(ky * 3 + kx) * HD + d0]);
+                            const f32x4 vv = *reinterpret_cast<const f32x4*>(&Vs[(r2 * br.W_sp + c2) * LDT + d0]);
+                            acc += wv * vv;
+                        }
+                    }
+                f32x4 out = o[df] * inv + acc;
+                *reinterpret_cast<f32x4*>(p.y + ((long)w.b * L + lq) * p.C + ch0 + d0) = out;
+            }
+            if (kq == 0) p.lse[((long)w.b * p.heads_total + br.head0 + w.g) * L + lq] = mx + __logf(sum);
+        }
+    }
+}
+
+// =====================================================================================
+// backward
+// =====================================================================================
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
+    constexpr int NP = 16 * NT;
+    constexpr int LDS_S = NP + 4;                 // dS row stride
+    constexpr int NTHREADS = 64 * NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qs = smem;                    // [NP][LDT]   (aliased by the LePE-gradient scratch at the end)
+    float* Ks = Qs + NP * LDT;
+    float* Vs = Ks + NP * LDT;
+    float* Ds = Vs + NP * LDT;           // dO
+    float* dSs = Ds + NP * LDT;          // [NP q][LDS_S]
+    float* lse_s = dSs + NP * LDS_S;     // [NP]
+    float* del_s = lse_s + NP;           // [NP]
+    float* Wl = del_s + NP;              // [9][32]
+
+    const WgInfo w = decode_wg(p, blockIdx.x);
+    const AttnBranch& br = p.br[w.bi];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int L = p.reso * p.reso, C3 = 3 * p.C;
+    const int ch0 = br.c0 + w.g * HD;
+    const int N = w.N;
+    const float* qkv_b = p.qkv + (long)w.b * L * C3;
+    const float* dy_b = p.dy + (long)w.b * L * p.C;
+    float* dqkv_b = p.dqkv + (long)w.b * L * C3;
+    const float* lse_b = p.lse + ((long)w.b * p.heads_total + br.head0 + w.g) * L;
+
+    for (int idx = tid; idx < NP * 8; idx += NTHREADS) {
+        const int row = idx >> 3, c4 = idx & 7;
+        f32x4 qv = {0.f, 0.f, 0.f, 0.f}, kv = qv, vv = qv, dv = qv;
+        if (row < N) {
+            const int l = token_of(br, w, p.reso, row);
+            const float* src = qkv_b + (long)l * C3 + ch0 + 4 * c4;
+            qv = *reinterpret_cast<const f32x4*>(src);
+            kv = *reinterpret_cast<const f32x4*>(src + p.C);
+            vv = *reinterpret_cast<const f32x4*>(src + 2 * p.C);
+            dv = *reinterpret_cast<const f32x4*>(dy_b + (long)l * p.C + ch0 + 4 * c4);
+        }
+        *reinterpret_cast<f32x4*>(&Qs[row * LDT + 4 * c4]) = qv;
+        *reinterpret_cast<f32x4*>(&Ks[row * LDT + 4 * c4]) = kv;
+        *reinterpret_cast<f32x4*>(&Vs[row * LDT + 4 * c4]) = vv;
+        *reinterpret_cast<f32x4*>(&Ds[row * LDT + 4 * c4]) = dv;
+    }
+    for (int t = tid; t < NP; t += NTHREADS) {
+        lse_s[t] = t < N ? lse_b[token_of(br, w, p.reso, t)] : INFINITY;   // +inf -> P = 0 on padded query rows
+        del_s[t] = 0.f;
+    }
+    for (int i = tid; i < 9 * HD; i += NTHREADS) {
+        const int tap = i / HD, ch = i - tap * HD;
+        Wl[i] = br.lepe_w[(ch0 - br.c0 + ch) * 9 + tap];
+    }
+    __syncthreads();
+
+    // ---- this wave's 16 keys: K and V fragments (B operands, key on the lane) ----
+    const int kw = wave;                               // key tile owned by this wave
+    const int tk = 16 * kw + li;                       // this lane's key token
+    float kf[8], vf[8];
+    {
+        const float* kp = &Ks[tk * LDT + 8 * kq];
+        const float* vp = &Vs[tk * LDT + 8 * kq];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            kf[e] = kp[e];
+            vf[e] = vp[e];
+        }
+    }
+    const bool kvalid = tk < N;
+
+    // ---- loop 1: P[q][key] and dP[q][key] for every query tile; delta[q] += sum_key P dP ----
+    f32x4 P[NT], dP[NT];
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+        const float* qp = &Qs[(16 * qt + li) * LDT + 8 * kq];
+        const float* dp = &Ds[(16 * qt + li) * LDT + 8 * kq];
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, da = sa;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sa = mfma4(qp[e], kf[e], sa);              // S[q][key] = sum_d Q[q][d] K[key][d]
+            da = mfma4(dp[e], vf[e], da);              // dP[q][key] = sum_d dO[q][d] V[key][d]
+        }
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_s[16 * qt + 4 * kq]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pv = kvalid ? __expf(sa[r] * p.scale - ls[r]) : 0.f;
+            sa[r] = pv;
+            float t = pv * da[r];
+            t += __shfl_xor(t, 1, 64);
+            t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 4, 64);
+            t += __shfl_xor(t, 8, 64);
+            if (li == 0) atomicAdd(&del_s[16 * qt + 4 * kq + r], t);
+        }
+        P[qt] = sa;
+        dP[qt] = da;
+    }
+    __syncthreads();
+
+    // ---- loop 2: dS = P o (dP - delta); dV^T += dO^T P; dK^T += Q^T dS; dS -> LDS ----
+    f32x4 dVt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 dKt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+        const f32x4 de = *reinterpret_cast<const f32x4*>(&del_s[16 * qt + 4 * kq]);
+        f32x4 ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[r] = P[qt][r] * (dP[qt][r] - de[r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qrow = 16 * qt + 4 * kq + r;
+            const float* dop = &Ds[qrow * LDT + li];
+            const float* qp = &Qs[qrow * LDT + li];
+            dVt[0] = mfma4(dop[0], P[qt][r], dVt[0]);
+            dVt[1] = mfma4(dop[16], P[qt][r], dVt[1]);
+            dKt[0] = mfma4(qp[0], ds[r], dKt[0]);
+            dKt[1] = mfma4(qp[16], ds[r], dKt[1]);
+            dSs[qrow * LDS_S + 16 * kw + li] = ds[r];
+        }
+    }
+    // lane holds dV^T / dK^T [d = 16 df + 4 kq + e][key = tk]: add LePE^T(dO) to dV and store
+    if (kvalid) {
+        const int lk = token_of(br, w, p.reso, tk);
+        const int rr = tk / br.W_sp, cc = tk - rr * br.W_sp;
+#pragma unroll
+        for (int df = 0; df < 2; ++df) {
+            const int d0 = 16 * df + 4 * kq;
+            f32x4 acc = dVt[df];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int r2 = rr - ky + 1, c2 = cc - kx + 1;   // output position that read this key through tap (ky,kx)
+                    if ((unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(&Wl[(ky * 3 + kx) * HD + d0]);
+                        const f32x4 dv = *reinterpret_cast<const f32x4*>(&Ds[(r2 * br.W_sp + c2) * LDT + d0]);
+                        acc += wv * dv;
+                    }
+                }
+            float* dst = dqkv_b + (long)lk * C3 + ch0 + d0;
+            *reinterpret_cast<f32x4*>(dst + p.C) = dKt[df] * p.scale;
+            *reinterpret_cast<f32x4*>(dst + 2 * p.C) = acc;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: dQ^T[d][q] = scale * sum_key K[key][d] dS[q][key]; this wave owns query tile `wave` ----
+    {
+        const int qt = wave;
+        f32x4 dQt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const f32x4 ds = *reinterpret_cast<const f32x4*>(&dSs[(16 * qt + li) * LDS_S + 16 * kt + 4 * kq]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* kp = &Ks[(16 * kt + 4 * kq + r) * LDT + li];
+                dQt[0] = mfma4(kp[0], ds[r], dQt[0]);
+                dQt[1] = mfma4(kp[16], ds[r], dQt[1]);
+            }
+        }
+        const int tq = 16 * qt + li;
+        if (tq < N) {
+            float* dst = dqkv_b + (long)token_of(br, w, p.reso, tq) * C3 + ch0 + 4 * kq;
+            *reinterpret_cast<f32x4*>(dst) = dQt[0] * p.scale;
+            *reinterpret_cast<f32x4*>(dst + 16) = dQt[1] * p.scale;
+        }
+    }
+
+    // ---- LePE weight / bias gradient partials of this (window, head): dw[tap][d], db[d] ----
+    // Qs is dead after loop 2 (barrier above): reuse it as [8][10][32] scratch.
+    float* scratch = Qs;
+    if (tid < 256) {
+        const int d = tid & 31, tg = tid >> 5;
+        float a[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) a[i] = 0.f;
+        for (int t = tg; t < N; t += 8) {
+            const float g = Ds[t * LDT + d];
+            const int rr = t / br.W_sp, cc = t - rr * br.W_sp;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int r2 = rr + ky - 1, c2 = cc + kx - 1;
+                    if ((unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp)
+                        a[ky * 3 + kx] += g * Vs[(r2 * br.W_sp + c2) * LDT + d];
+                }
+            a[9] += g;
+        }
+#pragma unroll
+        for (int i = 0; i < 10; ++i) scratch[(tg * 10 + i) * HD + d] = a[i];
+    }
+    __syncthreads();
+    for (int i = tid; i < 10 * HD; i += NTHREADS) {
+        float s = 0.f;
+#pragma unroll
+        for (int tg = 0; tg < 8; ++tg) s += scratch[tg * 10 * HD + i];
+        br.dw_part[(long)(blockIdx.x - br.wg_begin) * 10 * HD + i] = s;
+    }
+}
+
+// dw[cb][tap] / db[cb] = sum over (b, window) of the partial slabs.  One workgroup per (head, tap-or-bias).
+__global__ __launch_bounds__(256) void lepe_grad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                float* __restrict__ db, int heads, int nslab) {
+    __shared__ float red[256];
+    const int g = blockIdx.x / 10, i = blockIdx.x - g * 10;
+    const int d = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    float s = 0.f;
+    for (int sl = sg; sl < nslab; sl += 8) s += part[((long)sl * heads + g) * 10 * HD + i * HD + d];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k * 32 + d];
+        const int cb = g * HD + d;
+        if (i < 9) dw[cb * 9 + i] = t;
+        else db[cb] = t;
+    }
+}
+
+// =====================================================================================
+// standalone index-only window gather / scatter (img2windows / windows2img, cswin_unet.py:184-202)
+// =====================================================================================
+__global__ void img2windows_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int C, int H, int W,
+                                   int H_sp, int W_sp) {
+    // img (B, C, H, W) -> out (B*nH*nW, H_sp*W_sp, C)
+    const long total = (long)B * C * H * W;
+    const int nW = W / W_sp, nH = H / H_sp, N = H_sp * W_sp;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(o % C);
+        long t1 = o / C;
+        const int t = (int)(t1 % N);
+        long wi = t1 / N;
+        const int iw = (int)(wi % nW);
+        wi /= nW;
+        const int ih = (int)(wi % nH);
+        const int b = (int)(wi / nH);
+        const int r = t / W_sp, cc = t - r * W_sp;
+        out[o] = img[(((long)b * C + c) * H + ih * H_sp + r) * W + iw * W_sp + cc];
+    }
+}
+
+__global__ void windows2img_kernel(const float* __restrict__ win, float* __restrict__ out, int B, int C, int H, int W,
+                                   int H_sp, int W_sp) {
+    // win (B*nH*nW, H_sp*W_sp, C) -> out (B, H, W, C)
+    const long total = (long)B * C * H * W;
+    const int nW = W / W_sp, nH = H / H_sp, N = H_sp * W_sp;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(o % C);
+        long t1 = o / C;
+        const int x = (int)(t1 % W);
+        t1 /= W;
+        const int yy = (int)(t1 % H);
+        const int b = (int)(t1 / H);
+        const int ih = yy / H_sp, r = yy - ih * H_sp, iw = x / W_sp, cc = x - iw * W_sp;
+        out[o] = win[((((long)b * nH + ih) * nW + iw) * N + r * W_sp + cc) * C + c];
+    }
+}
+
+struct HostBranch { int idx; int heads; const float* w; const float* b; float* dw; float* db; };
+
+int fill_params(AttnParams& p, const char* who, int B, int reso, int C, int nbranch, const int* heads,
+                const int* idx, int split, float scale, int* ntile, int* nwg) {
+    CSWIN_REQUIRE(B > 0 && reso > 0 && C > 0 && (nbranch == 1 || nbranch == 2), CSWIN_ERR_SHAPE, "%s: bad arguments", who);
+    const int Cb = C / nbranch;
+    int heads_total = 0, wg = 0, N0 = -1;
+    for (int i = 0; i < nbranch; ++i) {
+        CSWIN_REQUIRE(heads[i] > 0 && Cb == heads[i] * HD, CSWIN_ERR_UNSUPPORTED,
+                      "%s: head dim %d unsupported (only %d)", who, heads[i] > 0 ? Cb / heads[i] : 0, HD);
+        int H_sp, W_sp;
+        if (idx[i] == -1) { H_sp = reso; W_sp = reso; }
+        else if (idx[i] == 0) { H_sp = reso; W_sp = split; }
+        else if (idx[i] == 1) { H_sp = split; W_sp = reso; }
+        else { cswin_set_error("%s: ERROR MODE %d", who, idx[i]); return CSWIN_ERR_SHAPE; }
+        CSWIN_REQUIRE(reso % H_sp == 0 && reso % W_sp == 0, CSWIN_ERR_SHAPE,
+                      "%s: resolution %d not divisible by window %dx%d", who, reso, H_sp, W_sp);
+        AttnBranch& br = p.br[i];
+        br.c0 = i * Cb;
+        br.heads = heads[i];
+        br.head0 = heads_total;
+        br.H_sp = H_sp; br.W_sp = W_sp;
+        br.nW = reso / W_sp;
+        br.nWin = (reso / H_sp) * (reso / W_sp);
+        br.wg_begin = wg;
+        wg += B * br.nWin * heads[i];
+        heads_total += heads[i];
+        if (N0 < 0) N0 = H_sp * W_sp;
+        CSWIN_REQUIRE(N0 == H_sp * W_sp, CSWIN_ERR_SHAPE, "%s: branches with different window sizes", who);
+    }
+    p.B = B; p.reso = reso; p.C = C; p.heads_total = heads_total; p.nbranch = nbranch;
+    p.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)HD);
+    *ntile = (N0 + 15) / 16;
+    *nwg = wg;
+    return CSWIN_OK;
+}
+
+template <int NT>
+int launch_fwd(const AttnParams& p, int nwg, hipStream_t st) {
+    constexpr int NW = NT < 8 ? NT : 8;
+    const size_t lds = (size_t)(2 * 16 * NT * LDT + 10 * HD) * sizeof(float);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { cswin_set_error("attn_fwd: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return CSWIN_ERR_HIP; }
+    }
+    hipLaunchKernelGGL((attn_fwd_kernel<NT>), dim3(nwg), dim3(64 * NW), lds, st, p);
+    return CSWIN_OK;
+}
+
+template <int NT>
+size_t bwd_lds_bytes() {
+    return (size_t)(4 * 16 * NT * LDT + 16 * NT * (16 * NT + 4) + 2 * 16 * NT + 9 * HD) * sizeof(float);
+}
+
+template <int NT>
+int launch_bwd(const AttnParams& p, int nwg, hipStream_t st) {
+    const size_t lds = bwd_lds_bytes<NT>();
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { cswin_set_error("attn_bwd: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return CSWIN_ERR_HIP; }
+    }
+    hipLaunchKernelGGL((attn_bwd_kernel<NT>), dim3(nwg), dim3(64 * NT), lds, st, p);
+    return CSWIN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// qkv (B, L, 3C) -> y (B, L, C), lse (B, heads_total, L).  nbranch = 2: branch i uses channels
+// [i*C/2, (i+1)*C/2) with stripe mode idx[i]; nbranch = 1: whole C, idx[0] (normally -1).
+int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, float* y, float* lse,
+                   int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split, float scale, void* stream) {
+    AttnParams p = {};
+    int nt, nwg;
+    int rc = fill_params(p, "attn_fwd", B, reso, C, nbranch, heads, idx, split, scale, &nt, &nwg);
+    if (rc) return rc;
+    CSWIN_REQUIRE(qkv && y && lse && lepe_w && lepe_b, CSWIN_ERR_SHAPE, "attn_fwd: null pointer");
+    for (int i = 0; i < nbranch; ++i) { p.br[i].lepe_w = lepe_w[i]; p.br[i].lepe_b = lepe_b[i]; }
+    p.qkv = qkv; p.y = y; p.lse = lse;
+    hipStream_t st = (hipStream_t)stream;
+    switch (nt) {
+        case 1: case 2: case 3: case 4: rc = launch_fwd<4>(p, nwg, st); break;
+        case 5: case 6: rc = launch_fwd<6>(p, nwg, st); break;
+        case 7: rc = launch_fwd<7>(p, nwg, st); break;
+        case 8: case 9: rc = launch_fwd<9>(p, nwg, st); break;
+        case 18: rc = launch_fwd<18>(p, nwg, st); break;
+        default:
+            cswin_set_error("attn_fwd: window of %d tokens unsupported", p.br[0].H_sp * p.br[0].W_sp);
+            return CSWIN_ERR_UNSUPPORTED;
+    }
+    if (rc) return rc;
+    CSWIN_LAUNCH_CHECK();
+    return CSWIN_OK;
+}
+
+size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split) {
+    AttnParams p = {};
+    int nt, nwg;
+    if (fill_params(p, "attn_bwd_workspace", B, reso, C, nbranch, heads, idx, split, 0.f, &nt, &nwg)) return 0;
+    return (size_t)nwg * 10 * HD * sizeof(float);
+}
+
+// dqkv (B, L, 3C) is fully overwritten; dlepe_w[i] (Cb,9) and dlepe_b[i] (Cb) are overwritten.
+int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* lse, const float* dy, float* dqkv,
+                   float* const* dlepe_w, float* const* dlepe_b, void* workspace, size_t ws_bytes, int B, int reso,
+                   int C, int nbranch, const int* heads, const int* idx, int split, float scale, void* stream) {
+    AttnParams p = {};
+    int nt, nwg;
+    int rc = fill_params(p, "attn_bwd", B, reso, C, nbranch, heads, idx, split, scale, &nt, &nwg);
+    if (rc) return rc;
+    CSWIN_REQUIRE(qkv && lse && dy && dqkv && lepe_w && dlepe_w && dlepe_b, CSWIN_ERR_SHAPE, "attn_bwd: null pointer");
+    CSWIN_REQUIRE(workspace && ws_bytes >= (size_t)nwg * 10 * HD * sizeof(float), CSWIN_ERR_WORKSPACE, "attn_bwd: workspace too small");
+    for (int i = 0; i < nbranch; ++i) {
+        p.br[i].lepe_w = lepe_w[i];
+        p.br[i].dw_part = (float*)workspace + (size_t)p.br[i].wg_begin * 10 * HD;
+    }
+    p.qkv = qkv; p.lse = const_cast<float*>(lse); p.dy = dy; p.dqkv = dqkv;
+    hipStream_t st = (hipStream_t)stream;
+    switch (nt) {
+        case 1: case 2: case 3: case 4: rc = launch_bwd<4>(p, nwg, st); break;
+        case 5: case 6: rc = launch_bwd<6>(p, nwg, st); break;
+        case 7: rc = launch_bwd<7>(p, nwg, st); break;
+        default:
+            cswin_set_error("attn_bwd: window of %d tokens unsupported (backward handles <= 112)", p.br[0].H_sp * p.br[0].W_sp);
+            return CSWIN_ERR_UNSUPPORTED;
+    }
+    if (rc) return rc;
+    CSWIN_LAUNCH_CHECK();
+    for (int i = 0; i < nbranch; ++i) {
+        const AttnBranch& br = p.br[i];
+        hipLaunchKernelGGL(lepe_grad_reduce_kernel, dim3(br.heads * 10), dim3(256), 0, st, br.dw_part, dlepe_w[i],
+                           dlepe_b[i], br.heads, B * br.nWin);
+    }
+    CSWIN_LAUNCH_CHECK();
+    return CSWIN_OK;
+}
+
+int cswin_img2windows(const float* img, float* out, int B, int C, int H, int W, int H_sp, int W_sp, void* stream) {
+    CSWIN_REQUIRE(img && out && B > 0 && C > 0 && H_sp > 0 && W_sp > 0 && H % H_sp == 0 && W % W_sp == 0, CSWIN_ERR_SHAPE,
+                  "img2windows: shape '[%d, %d, %d, %d]' is invalid for windows %dx%d", B, C, H, W, H_sp, W_sp);
+    long total = (long)B * C * H * W;
+    hipLaunchKernelGGL(img2windows_kernel, dim3(min((long)cdiv(total, 256), 4096L)), dim3(256), 0, (hipStream_t)stream, img, out, B, C, H, W, H_sp, W_sp);
+    CSWIN_LAUNCH_CHECK();
+    return CSWIN_OK;
+}
+
+int cswin_windows2img(const float* win, float* out, int B, int C, int H, int W, int H_sp, int W_sp, void* stream) {
+    CSWIN_REQUIRE(win && out && B > 0 && C > 0 && H_sp > 0 && W_sp > 0 && H % H_sp == 0 && W % W_sp == 0, CSWIN_ERR_SHAPE,
+                  "windows2img: bad shape");
+    long total = (long)B * C * H * W;
+    hipLaunchKernelGGL(windows2img_kernel, dim3(min((long)cdiv(total, 256), 4096L)), dim3(256), 0, (hipStream_t)stream, win, out, B, C, H, W, H_sp, W_sp);
+    CSWIN_LAUNCH_CHECK();
+    return CSWIN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// Shared device/host helpers for libcswin_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CSWIN_OK 0
+#define CSWIN_ERR_SHAPE (-1)
+#define CSWIN_ERR_ALIGN (-2)
+#define CSWIN_ERR_WORKSPACE (-3)
+#define CSWIN_ERR_HIP (-4)
+#define CSWIN_ERR_UNSUPPORTED (-5)
+
+// thread-local message buffer behind cswin_last_error()
+void cswin_set_error(const char* fmt, ...);
+
+#define CSWIN_REQUIRE(cond, code, ...)          \
+    do {                                        \
+        if (!(cond)) {                          \
+            cswin_set_error(__VA_ARGS__);       \
+            return (code);                      \
+        }                                       \
+    } while (0)
+
+#define CSWIN_LAUNCH_CHECK()                                                   \
+    do {                                                                       \
+        hipError_t e__ = hipGetLastError();                                    \
+        if (e__ != hipSuccess) {                                               \
+            cswin_set_error("%s:%d HIP launch error: %s", __FILE__, __LINE__,  \
+                            hipGetErrorString(e__));                           \
+            return CSWIN_ERR_HIP;                                              \
+        }                                                                      \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact (erf) GELU, matching torch.nn.GELU() default, and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}

@@ -1,0 +1,207 @@
+// LayerNorm over the channel axis of (M, C) token matrices (cswin_unet.py:168,179,218,341,497,533).
+// HBM-bound: one pass over x forward (16-B loads, a row lives in registers), one pass over (dy, x)
+// backward with the residual-path gradient add fused in and dgamma/dbeta reduced through
+// per-workgroup partial slabs (deterministic, no atomics).
+#include "common.h"
+
+namespace {
+
+// LPR lanes cooperate on one row, each holding VPL float4 (C = 4 * LPR * VPL)
+template <int LPR, int VPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ y,
+                                                      float* __restrict__ mean, float* __restrict__ rstd, int M,
+                                                      float eps) {
+    constexpr int C = 4 * LPR * VPL;
+    constexpr int RPB = 256 / LPR;                    // rows per block pass
+    const int sub = threadIdx.x % LPR, rib = threadIdx.x / LPR;
+    f32x4 g[VPL], b[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        g[v] = *reinterpret_cast<const f32x4*>(gamma + 4 * (sub + v * LPR));
+        b[v] = *reinterpret_cast<const f32x4*>(beta + 4 * (sub + v * LPR));
+    }
+    for (long row = (long)blockIdx.x * RPB + rib; row < M; row += (long)gridDim.x * RPB) {
+        f32x4 xv[VPL];
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            xv[v] = *reinterpret_cast<const f32x4*>(x + row * C + 4 * (sub + v * LPR));
+            s += xv[v][0] + xv[v][1] + xv[v][2] + xv[v][3];
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mu = s * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float d = xv[v][e] - mu;
+                q += d * d;
+            }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rs = rsqrtf(q * (1.0f / C) + eps);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            f32x4 o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o4[e] = (xv[v][e] - mu) * rs * g[v][e] + b[v][e];
+            *reinterpret_cast<f32x4*>(y + row * C + 4 * (sub + v * LPR)) = o4;
+        }
+        if (sub == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+    }
+}
+
+// dx = dres + rstd * (g*dy - mean_c(g*dy) - xhat * mean_c(g*dy*xhat));  partial[blk] = {sum dy*xhat, sum dy}
+template <int LPR, int VPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                      float* __restrict__ dx, float* __restrict__ partial, int M) {
+    constexpr int C = 4 * LPR * VPL;
+    constexpr int RPB = 256 / LPR;
+    __shared__ float red[2 * RPB * C];
+    const int sub = threadIdx.x % LPR, rib = threadIdx.x / LPR;
+    f32x4 g[VPL], dg[VPL], db[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        g[v] = *reinterpret_cast<const f32x4*>(gamma + 4 * (sub + v * LPR));
+        dg[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (long row = (long)blockIdx.x * RPB + rib; row < M; row += (long)gridDim.x * RPB) {
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[VPL], gy[VPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const long off = row * C + 4 * (sub + v * LPR);
+            f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+            f32x4 dv = *reinterpret_cast<const f32x4*>(dy + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[v][e] = (xv[e] - mu) * rs;
+                gy[v][e] = dv[e] * g[v][e];
+                s1 += gy[v][e];
+                s2 += gy[v][e] * xh[v][e];
+                dg[v][e] += dv[e] * xh[v][e];
+                db[v][e] += dv[e];
+            }
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+        }
+        s1 *= (1.0f / C);
+        s2 *= (1.0f / C);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const long off = row * C + 4 * (sub + v * LPR);
+            f32x4 o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o4[e] = rs * (gy[v][e] - s1 - xh[v][e] * s2);
+            if (dres) o4 += *reinterpret_cast<const f32x4*>(dres + off);
+            *reinterpret_cast<f32x4*>(dx + off) = o4;
+        }
+    }
+    // reduce the RPB row-groups of this block, then write one partial slab
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (sub + v * LPR) + e;
+            red[rib * C + c] = dg[v][e];
+            red[RPB * C + rib * C + c] = db[v][e];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += 256) {
+        const int which = c / C, cc = c - which * C;
+        float s = 0.f;
+        for (int r = 0; r < RPB; ++r) s += red[which * RPB * C + r * C + cc];
+        partial[(long)blockIdx.x * 2 * C + c] = s;
+    }
+}
+
+__global__ void ln_reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                          float* __restrict__ dbeta, int C, int nblk) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * C) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(long)b * 2 * C + c];
+    if (c < C) dgamma[c] = s;
+    else dbeta[c - C] = s;
+}
+
+int ln_grid(int M, int rpb) { return min(cdiv(M, rpb), 1024); }
+
+template <int LPR, int VPL>
+void launch_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int M, float eps,
+                hipStream_t st) {
+    hipLaunchKernelGGL((ln_fwd_kernel<LPR, VPL>), dim3(ln_grid(M, 256 / LPR)), dim3(256), 0, st, x, g, b, y, mean, rstd, M, eps);
+}
+template <int LPR, int VPL>
+void launch_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* g,
+                const float* dres, float* dx, float* partial, int M, hipStream_t st) {
+    hipLaunchKernelGGL((ln_bwd_kernel<LPR, VPL>), dim3(ln_grid(M, 256 / LPR)), dim3(256), 0, st, dy, x, mean, rstd, g, dres, dx, partial, M);
+}
+
+bool ln_supported(int C) { return C == 64 || C == 128 || C == 256 || C == 512 || C == 32 || C == 1024; }
+
+}  // namespace
+
+extern "C" {
+
+int cswin_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                        int M, int C, float eps, void* stream) {
+    CSWIN_REQUIRE(x && gamma && beta && y && mean && rstd && M > 0, CSWIN_ERR_SHAPE, "layernorm_fwd: bad arguments");
+    CSWIN_REQUIRE(ln_supported(C), CSWIN_ERR_UNSUPPORTED, "layernorm: C=%d not in {32,64,128,256,512,1024}", C);
+    hipStream_t st = (hipStream_t)stream;
+    switch (C) {
+        case 32: launch_fwd<8, 1>(x, gamma, beta, y, mean, rstd, M, eps, st); break;
+        case 64: launch_fwd<16, 1>(x, gamma, beta, y, mean, rstd, M, eps, st); break;
+        case 128: launch_fwd<32, 1>(x, gamma, beta, y, mean, rstd, M, eps, st); break;
+        case 256: launch_fwd<64, 1>(x, gamma, beta, y, mean, rstd, M, eps, st); break;
+        case 512: launch_fwd<64, 2>(x, gamma, beta, y, mean, rstd, M, eps, st); break;
+        case 1024: launch_fwd<64, 4>(x, gamma, beta, y, mean, rstd, M, eps, st); break;
+    }
+    CSWIN_LAUNCH_CHECK();
+    return CSWIN_OK;
+}
+
+size_t cswin_layernorm_bwd_workspace(int M, int C) {
+    int lpr = C / 4 > 64 ? 64 : C / 4;
+    return (size_t)ln_grid(M, 256 / lpr) * 2 * C * sizeof(float);
+}
+
+// dres may be NULL; dx may alias dres.  dgamma/dbeta are overwritten.
+int cswin_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                        const float* dres, float* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes,
+                        int M, int C, void* stream) {
+    CSWIN_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && M > 0, CSWIN_ERR_SHAPE, "layernorm_bwd: bad arguments");
+    CSWIN_REQUIRE(ln_supported(C), CSWIN_ERR_UNSUPPORTED, "layernorm: C=%d not in {32,64,128,256,512,1024}", C);
+    CSWIN_REQUIRE(workspace && ws_bytes >= cswin_layernorm_bwd_workspace(M, C), CSWIN_ERR_WORKSPACE, "layernorm_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    int lpr = C / 4 > 64 ? 64 : C / 4;
+    int nblk = ln_grid(M, 256 / lpr);
+    switch (C) {
+        case 32: launch_bwd<8, 1>(dy, x, mean, rstd, gamma, dres, dx, partial, M, st); break;
+        case 64: launch_bwd<16, 1>(dy, x, mean, rstd, gamma, dres, dx, partial, M, st); break;
+        case 128: launch_bwd<32, 1>(dy, x, mean, rstd, gamma, dres, dx, partial, M, st); break;
+        case 256: launch_bwd<64, 1>(dy, x, mean, rstd, gamma, dres, dx, partial, M, st); break;
+        case 512: launch_bwd<64, 2>(dy, x, mean, rstd, gamma, dres, dx, partial, M, st); break;
+        case 1024: launch_bwd<64, 4>(dy, x, mean, rstd, gamma, dres, dx, partial, M, st); break;
+    }
+    CSWIN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ln_reduce_partials_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, partial, dgamma, dbeta, C, nblk);
+    CSWIN_LAUNCH_CHECK();
+    return CSWIN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// Optimiser side of the step: SGD with momentum and weight decay (trainer.py:42, torch.optim.SGD
+// semantics) over ONE flat parameter buffer, plus the multi-tensor gather that packs the per-tensor
+// gradients into the flat gradient buffer that RCCL all-reduces.  One launch each instead of 463.
+//   g' = g * grad_scale + wd * p ;  m = mu * m + g' ;  p -= lr * m      (m starts at 0, so step 1 gives m = g')
+// lr is read from DEVICE memory so a captured hipGraph can be replayed under the poly schedule.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sgd_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, long n, const float* __restrict__ lr_dev,
+                                                        float momentum, float wd, float grad_scale) {
+    const float lr = lr_dev[0];
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+        mv = momentum * mv + (gv * grad_scale + wd * pv);
+        pv -= lr * mv;
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float mv = momentum * m[i] + (g[i] * grad_scale + wd * p[i]);
+        m[i] = mv;
+        p[i] -= lr * mv;
+    }
+}
+
+struct CopyChunk { const float* src; float* dst; long n; };
+
+// table[i] = {src, dst, n}: one workgroup per chunk (chunks are <= 16384 floats)
+__global__ __launch_bounds__(256) void multi_copy_kernel(const CopyChunk* __restrict__ table) {
+    const CopyChunk c = table[blockIdx.x];
+    const bool vec = (((uintptr_t)c.src | (uintptr_t)c.dst) & 15) == 0;
+    if (vec) {
+        const long n4 = c.n / 4;
+        for (long i = threadIdx.x; i < n4; i += 256) reinterpret_cast<f32x4*>(c.dst)[i] = reinterpret_cast<const f32x4*>(c.src)[i];
+        for (long i = n4 * 4 + threadIdx.x; i < c.n; i += 256) c.dst[i] = c.src[i];
+    } else {
+        for (long i = threadIdx.x; i < c.n; i += 256) c.dst[i] = c.src[i];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cswin_sgd_flat(float* p, const float* g, float* m, long n, const float* lr_dev, float momentum, float weight_decay,
+                   float grad_scale, void* stream) {
+    CSWIN_REQUIRE(p && g && m && lr_dev && n > 0, CSWIN_ERR_SHAPE, "sgd_flat: bad arguments");
+    CSWIN_REQUIRE(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m)) & 15) == 0, CSWIN_ERR_ALIGN, "sgd_flat: buffers must be 16-B aligned");
+    long b = (n / 4 + 255) / 256;
+    int grid = (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+    hipLaunchKernelGGL(sgd_flat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, n, lr_dev, momentum, weight_decay, grad_scale);
+    CSWIN_LAUNCH_CHECK();
+    return CSWIN_OK;
+}
+
+// table: device array of nchunks {const float* src; float* dst; int64 n} records (24 bytes each)
+int cswin_multi_copy(const void* table, int nchunks, void* stream) {
+    CSWIN_REQUIRE(table && nchunks > 0, CSWIN_ERR_SHAPE, "multi_copy: bad arguments");
+    hipLaunchKernelGGL(multi_copy_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const CopyChunk*)table);
+    CSWIN_LAUNCH_CHECK();
+    return CSWIN_OK;
+}
+
+}  // extern "C"

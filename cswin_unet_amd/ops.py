@@ -1,0 +1,492 @@
+"""torch.autograd.Function wrappers over the C ABI (include/cswin_hip.h).
+
+PyTorch is plumbing here: it owns device memory (caching allocator), the autograd tape and the
+current stream.  All arithmetic of the hot path happens in libcswin_hip.so.  Every op raises
+CswinHipError on a non-HIP tensor -- there is no CPU / eager fallback.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ._lib import call, dev_f32, lib, ptr, stream
+
+__all__ = ["layer_norm", "linear", "mlp", "stripe_attention", "conv_tokens", "patch_embed_conv", "carafe_reassemble",
+           "tokens_to_nchw", "matmul_nn", "ce_dice_loss", "img2windows", "windows2img"]
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16) // 4 + 4, dtype=torch.float32, device=device)
+
+
+def _int_array(vals):
+    return (ctypes.c_int * len(vals))(*vals)
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm
+# ------------------------------------------------------------------------------------------------
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x, gamma, beta = dev_f32(x, "layer_norm input"), dev_f32(gamma), dev_f32(beta)
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        call("cswin_layernorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), M, C, eps, stream())
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dy = dev_f32(dy)
+        C = x.shape[-1]
+        M = x.numel() // C
+        dx = torch.empty_like(x)
+        dg = torch.empty_like(gamma)
+        db = torch.empty_like(gamma)
+        nbytes = lib().cswin_layernorm_bwd_workspace(M, C)
+        ws = _ws(nbytes, x.device)
+        call("cswin_layernorm_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), None, ptr(dx), ptr(dg), ptr(db),
+             ptr(ws), nbytes, M, C, stream())
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear (+ fused skip-concat input, residual / DropPath epilogue)
+# ------------------------------------------------------------------------------------------------
+def _rows_per_sample(x):
+    return x.numel() // (x.shape[0] * x.shape[-1])
+
+
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, x2, residual, row_scale):
+        x, w = dev_f32(x, "linear input"), dev_f32(w, "linear weight")
+        b, x2, residual, row_scale = dev_f32(b), dev_f32(x2), dev_f32(residual), dev_f32(row_scale)
+        K1 = x.shape[-1]
+        K = K1 + (x2.shape[-1] if x2 is not None else 0)
+        N = w.shape[0]
+        assert w.shape[1] == K, f"linear: weight {tuple(w.shape)} vs input features {K}"
+        M = x.numel() // K1
+        y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+        rps = _rows_per_sample(x) if row_scale is not None else 1
+        call("cswin_linear_fwd", ptr(x), ptr(x2), K1 if x2 is not None else 0, ptr(w), ptr(b), ptr(y), None, ptr(residual),
+             ptr(row_scale), rps, M, N, K, stream())
+        ctx.save_for_backward(x, w, x2, row_scale)
+        ctx.has_bias, ctx.has_res, ctx.rps = b is not None, residual is not None, rps
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w, x2, row_scale = ctx.saved_tensors
+        dy = dev_f32(dy)
+        K1 = x.shape[-1]
+        N, K = w.shape
+        M = x.numel() // K1
+        need = ctx.needs_input_grad
+        dx = dx2 = dw = db = None
+        if need[0] or (x2 is not None and need[3]):
+            dx = torch.empty_like(x)
+            dx2 = torch.empty_like(x2) if x2 is not None else None
+            call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), ptr(dx2), K1 if x2 is not None else 0, None,
+                 ptr(row_scale), ctx.rps, None, M, N, K, stream())
+        if need[1]:
+            dw = torch.empty_like(w)
+            db = torch.empty(N, dtype=torch.float32, device=w.device) if ctx.has_bias else None
+            nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
+            ws = _ws(nbytes, w.device)
+            call("cswin_linear_bwd_weight", ptr(dy), ptr(x), ptr(x2), K1 if x2 is not None else 0, ptr(row_scale), ctx.rps,
+                 ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, stream())
+        dres = dy if ctx.has_res else None
+        return dx, dw, db, dx2, dres, None
+
+
+def linear(x, w, b=None, x2=None, residual=None, row_scale=None):
+    """y = [x | x2] @ w^T + b;  with residual: y = residual + row_scale[sample] * (...)  (DropPath + skip add)."""
+    return _Linear.apply(x, w, b, x2, residual, row_scale)
+
+
+class _Mlp(Function):
+    """fc1 -> GELU(erf) -> fc2 (cswin_unet.py:22-28) with the optional residual/DropPath epilogue of :179."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual, row_scale):
+        x, w1, b1, w2, b2 = (dev_f32(t) for t in (x, w1, b1, w2, b2))
+        residual, row_scale = dev_f32(residual), dev_f32(row_scale)
+        K = x.shape[-1]
+        Hd, N = w1.shape[0], w2.shape[0]
+        M = x.numel() // K
+        pre = torch.empty(x.shape[:-1] + (Hd,), dtype=torch.float32, device=x.device)
+        act = torch.empty_like(pre)
+        call("cswin_linear_fwd", ptr(x), None, 0, ptr(w1), ptr(b1), ptr(pre), ptr(act), None, None, 1, M, Hd, K, stream())
+        y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+        rps = _rows_per_sample(x) if row_scale is not None else 1
+        call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(b2), ptr(y), None, ptr(residual), ptr(row_scale), rps,
+             M, N, Hd, stream())
+        ctx.save_for_backward(x, w1, w2, pre, act, row_scale)
+        ctx.has_res, ctx.rps, ctx.has_b1, ctx.has_b2 = residual is not None, rps, b1 is not None, b2 is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w1, w2, pre, act, row_scale = ctx.saved_tensors
+        dy = dev_f32(dy)
+        K = x.shape[-1]
+        Hd, N = w1.shape[0], w2.shape[0]
+        M = x.numel() // K
+        dev = x.device
+        st = stream()
+        # d pre = (row_scale * dy @ w2) * gelu'(pre)   (GELU backward fused into the data-gradient epilogue)
+        dpre = torch.empty_like(pre)
+        call("cswin_linear_bwd_data", ptr(dy), ptr(w2), ptr(dpre), None, 0, ptr(pre), ptr(row_scale), ctx.rps, None, M, N,
+             Hd, st)
+        dw2 = torch.empty_like(w2)
+        db2 = torch.empty(N, dtype=torch.float32, device=dev) if ctx.has_b2 else None
+        nbytes = max(lib().cswin_linear_bwd_weight_workspace(M, N, Hd), lib().cswin_linear_bwd_weight_workspace(M, Hd, K))
+        ws = _ws(nbytes, dev)
+        call("cswin_linear_bwd_weight", ptr(dy), ptr(act), None, 0, ptr(row_scale), ctx.rps, ptr(dw2), ptr(db2), ptr(ws),
+             nbytes, M, N, Hd, st)
+        dw1 = torch.empty_like(w1)
+        db1 = torch.empty(Hd, dtype=torch.float32, device=dev) if ctx.has_b1 else None
+        call("cswin_linear_bwd_weight", ptr(dpre), ptr(x), None, 0, None, 1, ptr(dw1), ptr(db1), ptr(ws), nbytes, M, Hd, K, st)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            call("cswin_linear_bwd_data", ptr(dpre), ptr(w1), ptr(dx), None, 0, None, None, 1, None, M, Hd, K, st)
+        return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None
+
+
+def mlp(x, w1, b1, w2, b2, residual=None, row_scale=None):
+    return _Mlp.apply(x, w1, b1, w2, b2, residual, row_scale)
+
+
+class _MatmulNN(Function):
+    """c (M, K) = a (M, N) @ b (N, K) -- used to compose the 1x1 `output` head with upsample1.out."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = dev_f32(a), dev_f32(b)
+        M, N = a.shape
+        K = b.shape[1]
+        c = torch.empty(M, K, dtype=torch.float32, device=a.device)
+        call("cswin_linear_bwd_data", ptr(a), ptr(b), ptr(c), None, 0, None, None, 1, None, M, N, K, stream())
+        ctx.save_for_backward(a, b)
+        return c
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        dc = dev_f32(dc)
+        M, N = a.shape
+        K = b.shape[1]
+        da = torch.empty_like(a)        # da = dc @ b^T
+        call("cswin_linear_fwd", ptr(dc), None, 0, ptr(b), None, ptr(da), None, None, None, 1, M, N, K, stream())
+        db = torch.empty_like(b)        # db (N, K) = a^T @ dc
+        nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
+        ws = _ws(nbytes, a.device)
+        call("cswin_linear_bwd_weight", ptr(a), ptr(dc), None, 0, None, 1, ptr(db), None, ptr(ws), nbytes, M, N, K, stream())
+        return da, db
+
+
+def matmul_nn(a, b):
+    return _MatmulNN.apply(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused stripe attention
+# ------------------------------------------------------------------------------------------------
+class _StripeAttention(Function):
+    @staticmethod
+    def forward(ctx, qkv, reso, split, idx, heads, scale, *wb):
+        qkv = dev_f32(qkv, "attention qkv")
+        nb = len(idx)
+        ws_ = [dev_f32(t).view(t.shape[0], 9) for t in wb[:nb]]
+        bs_ = [dev_f32(t) for t in wb[nb:]]
+        B, L, C3 = qkv.shape
+        C = C3 // 3
+        if L != reso * reso:
+            raise ValueError("flatten img_tokens has wrong size")
+        y = torch.empty(B, L, C, dtype=torch.float32, device=qkv.device)
+        lse = torch.empty(B, sum(heads), L, dtype=torch.float32, device=qkv.device)
+        call("cswin_attn_fwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(y), ptr(lse), B, reso, C, nb,
+             _int_array(heads), _int_array(idx), split, float(scale or 0.0), stream())
+        ctx.save_for_backward(qkv, lse, *ws_)
+        ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        qkv, lse, *ws_ = ctx.saved_tensors
+        reso, split, idx, heads, scale = ctx.meta
+        dy = dev_f32(dy)
+        nb = len(idx)
+        B, L, C3 = qkv.shape
+        C = C3 // 3
+        dqkv = torch.empty_like(qkv)
+        dws = [torch.empty_like(w) for w in ws_]
+        dbs = [torch.empty(w.shape[0], dtype=torch.float32, device=qkv.device) for w in ws_]
+        ha, ia = _int_array(heads), _int_array(idx)
+        nbytes = lib().cswin_attn_bwd_workspace(B, reso, C, nb, ha, ia, split)
+        ws = _ws(nbytes, qkv.device)
+        call("cswin_attn_bwd", ptr(qkv), _ptr_array(ws_), ptr(lse), ptr(dy), ptr(dqkv), _ptr_array(dws), _ptr_array(dbs),
+             ptr(ws), nbytes, B, reso, C, nb, ha, ia, split, scale, stream())
+        return (dqkv, None, None, None, None, None) + tuple(d.view(d.shape[0], 1, 3, 3) for d in dws) + tuple(dbs)
+
+
+def stripe_attention(qkv, reso, split, idx, heads, lepe_w, lepe_b, scale=None):
+    """qkv (B, L, 3C) -> (B, L, C).  idx/heads/lepe_w/lepe_b: one entry per branch."""
+    return _StripeAttention.apply(qkv, reso, split, tuple(idx), tuple(heads), scale, *lepe_w, *lepe_b)
+
+
+# ------------------------------------------------------------------------------------------------
+# convolutions on tokens
+# ------------------------------------------------------------------------------------------------
+def _permute_w(w, cpad, want_t):
+    Cout, Cin, ks, _ = w.shape
+    wp = torch.empty(Cout, ks * ks, cpad, dtype=torch.float32, device=w.device)
+    wpt = torch.empty(ks * ks, Cout, cpad, dtype=torch.float32, device=w.device) if want_t else None
+    call("cswin_conv_weight_permute", ptr(w), ptr(wp), ptr(wpt), Cout, Cin, ks, cpad, stream())
+    return wp, wpt
+
+
+class _ConvTokens(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, H, W, stride, pad):
+        x, w, b = dev_f32(x, "conv input"), dev_f32(w), dev_f32(b)
+        B, L, Cin = x.shape
+        assert L == H * W and w.shape[1] == Cin
+        Cout, ks = w.shape[0], w.shape[2]
+        OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+        wp, _ = _permute_w(w, Cin, False)
+        y = torch.empty(B, OH * OW, Cout, dtype=torch.float32, device=x.device)
+        call("cswin_conv_tok_fwd", ptr(x), ptr(wp), ptr(b), ptr(y), B, H, W, Cin, Cout, ks, stride, pad, stream())
+        ctx.save_for_backward(x, w)
+        ctx.meta = (H, W, stride, pad, b is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        H, W, stride, pad, has_b = ctx.meta
+        dy = dev_f32(dy)
+        B, L, Cin = x.shape
+        Cout, ks = w.shape[0], w.shape[2]
+        st = stream()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            _, wpt = _permute_w(w, Cin, True)
+            dx = torch.empty_like(x)
+            call("cswin_conv_tok_bwd_data", ptr(dy), ptr(wpt), ptr(dx), B, H, W, Cin, Cout, ks, stride, pad, st)
+        dwp = torch.empty(Cout, ks * ks, Cin, dtype=torch.float32, device=x.device)
+        db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_b else None
+        nbytes = lib().cswin_conv_tok_bwd_weight_workspace(B, H, W, Cin, Cout, ks, stride, pad)
+        ws = _ws(nbytes, x.device)
+        call("cswin_conv_tok_bwd_weight", ptr(dy), ptr(x), ptr(dwp), ptr(db), ptr(ws), nbytes, B, H, W, Cin, Cout, ks, stride,
+             pad, st)
+        dw = torch.empty_like(w)
+        call("cswin_conv_weight_unpermute", ptr(dwp), ptr(dw), Cout, Cin, ks, Cin, st)
+        return dx, dw, db, None, None, None, None
+
+
+def conv_tokens(x, w, b, H, W, stride, pad):
+    """nn.Conv2d(w, b, stride, pad) applied to tokens x (B, H*W, Cin) -> (B, OH*OW, Cout)."""
+    return _ConvTokens.apply(x, w, b, H, W, stride, pad)
+
+
+class _PatchEmbedConv(Function):
+    """Conv2d(in_chans, E, 7, 4, 2) on an NCHW image -> tokens (cswin_unet.py:339-340); no input gradient."""
+
+    @staticmethod
+    def forward(ctx, img, w, b, stride, pad):
+        img, w, b = dev_f32(img, "image"), dev_f32(w), dev_f32(b)
+        B, Cin, H, W = img.shape
+        Cout, ks = w.shape[0], w.shape[2]
+        cpad = (Cin + 3) // 4 * 4
+        st = stream()
+        x = torch.empty(B, H * W, cpad, dtype=torch.float32, device=img.device)
+        call("cswin_nchw_to_tokens", ptr(img), ptr(x), B, Cin, H, W, cpad, st)
+        wp, _ = _permute_w(w, cpad, False)
+        OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+        y = torch.empty(B, OH * OW, Cout, dtype=torch.float32, device=img.device)
+        call("cswin_conv_tok_fwd", ptr(x), ptr(wp), ptr(b), ptr(y), B, H, W, cpad, Cout, ks, stride, pad, st)
+        ctx.save_for_backward(x, w)
+        ctx.meta = (H, W, stride, pad, cpad, b is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        H, W, stride, pad, cpad, has_b = ctx.meta
+        dy = dev_f32(dy)
+        B = x.shape[0]
+        Cout, Cin, ks, _ = w.shape
+        st = stream()
+        dwp = torch.empty(Cout, ks * ks, cpad, dtype=torch.float32, device=x.device)
+        db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_b else None
+        nbytes = lib().cswin_conv_tok_bwd_weight_workspace(B, H, W, cpad, Cout, ks, stride, pad)
+        ws = _ws(nbytes, x.device)
+        call("cswin_conv_tok_bwd_weight", ptr(dy), ptr(x), ptr(dwp), ptr(db), ptr(ws), nbytes, B, H, W, cpad, Cout, ks, stride,
+             pad, st)
+        dw = torch.empty_like(w)
+        call("cswin_conv_weight_unpermute", ptr(dwp), ptr(dw), Cout, Cin, ks, cpad, st)
+        return None, dw, db, None, None
+
+
+def patch_embed_conv(img, w, b, stride=4, pad=2):
+    return _PatchEmbedConv.apply(img, w, b, stride, pad)
+
+
+# ------------------------------------------------------------------------------------------------
+# CARAFE reassembly, layout adapters
+# ------------------------------------------------------------------------------------------------
+class _CarafeReassemble(Function):
+    @staticmethod
+    def forward(ctx, e, z, bias, H, W, S):
+        e, z, bias = dev_f32(e, "carafe kernel logits"), dev_f32(z, "carafe features"), dev_f32(bias)
+        B, L, Cz = z.shape
+        assert L == H * W and e.shape == (B, L, 9 * S * S)
+        out = torch.empty(B, L * S * S, Cz, dtype=torch.float32, device=z.device)
+        wt = torch.empty_like(e)
+        call("cswin_carafe_fwd", ptr(e), ptr(z), ptr(bias), ptr(out), ptr(wt), B, H, W, Cz, S, stream())
+        ctx.save_for_backward(z, wt)
+        ctx.meta = (H, W, S, bias is not None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        z, wt = ctx.saved_tensors
+        H, W, S, has_b = ctx.meta
+        dout = dev_f32(dout)
+        B, L, Cz = z.shape
+        de = torch.empty_like(wt)
+        dz = torch.empty_like(z)
+        db = torch.empty(Cz, dtype=torch.float32, device=z.device) if has_b else None
+        nbytes = lib().cswin_carafe_bwd_workspace(B, H, W, Cz, S)
+        ws = _ws(nbytes, z.device)
+        call("cswin_carafe_bwd", ptr(dout), ptr(z), ptr(wt), ptr(de), ptr(dz), ptr(db), ptr(ws), nbytes, B, H, W, Cz, S, stream())
+        return de, dz, db, None, None, None
+
+
+def carafe_reassemble(e, z, bias, H, W, S):
+    return _CarafeReassemble.apply(e, z, bias, H, W, S)
+
+
+class _TokensToNchw(Function):
+    @staticmethod
+    def forward(ctx, x, C, H, W):
+        x = dev_f32(x)
+        B, L, Cpad = x.shape
+        assert L == H * W and C <= Cpad
+        y = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+        call("cswin_tokens_to_nchw", ptr(x), ptr(y), B, C, H, W, Cpad, stream())
+        ctx.meta = (C, H, W, Cpad)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        C, H, W, Cpad = ctx.meta
+        dy = dev_f32(dy)
+        B = dy.shape[0]
+        dx = torch.empty(B, H * W, Cpad, dtype=torch.float32, device=dy.device)
+        call("cswin_nchw_to_tokens", ptr(dy), ptr(dx), B, C, H, W, Cpad, stream())
+        return dx, None, None, None
+
+
+def tokens_to_nchw(x, C, H, W):
+    """(B, H*W, Cpad) tokens -> (B, C, H, W) taking the first C channels."""
+    return _TokensToNchw.apply(x, C, H, W)
+
+
+def img2windows(img, H_sp, W_sp):
+    """img (B, C, H, W) -> (B*nH*nW, H_sp*W_sp, C)   (cswin_unet.py:184-191); index-only."""
+    img = dev_f32(img, "img2windows input")
+    B, C, H, W = img.shape
+    out = torch.empty(B * (H // H_sp) * (W // W_sp), H_sp * W_sp, C, dtype=torch.float32, device=img.device)
+    call("cswin_img2windows", ptr(img), ptr(out), B, C, H, W, H_sp, W_sp, stream())
+    return out
+
+
+def windows2img(img_splits_hw, H_sp, W_sp, H, W):
+    """(B', H_sp*W_sp, C) windows -> (B, H, W, C)   (cswin_unet.py:194-202); index-only."""
+    x = dev_f32(img_splits_hw, "windows2img input")
+    C = x.shape[-1]
+    B = int(x.shape[0] / (H * W / H_sp / W_sp))
+    out = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
+    call("cswin_windows2img", ptr(x), ptr(out), B, C, H, W, H_sp, W_sp, stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# loss
+# ------------------------------------------------------------------------------------------------
+class _CeDiceLoss(Function):
+    @staticmethod
+    def forward(ctx, logits, labels, w_ce, w_dice, group):
+        logits = dev_f32(logits, "logits")
+        labels = labels.contiguous()
+        if labels.dtype != torch.int64:
+            labels = labels.long()
+        B, ncls = logits.shape[:2]
+        HW = logits.numel() // (B * ncls)
+        dev = logits.device
+        st = stream()
+        nbytes = lib().cswin_loss_workspace(B, ncls, HW)
+        ws = _ws(nbytes, dev)
+        sums = torch.empty(1 + 3 * ncls, dtype=torch.float32, device=dev)
+        call("cswin_loss_sums", ptr(logits), ptr(labels), ptr(sums), ptr(ws), nbytes, B, ncls, HW, st)
+        world = 1
+        if group is not None:
+            import torch.distributed as dist
+            world = dist.get_world_size(group)
+            if world > 1:
+                dist.all_reduce(sums, group=group)      # 1 + 3*ncls floats: the reference's global-batch Dice
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        coef = torch.empty(2 * ncls, dtype=torch.float32, device=dev)
+        call("cswin_loss_finalize", ptr(sums), ptr(out), ptr(coef), float(B * HW * world), ncls, w_ce, w_dice, stream())
+        ctx.save_for_backward(logits, labels, coef)
+        # gradients are averaged over ranks afterwards: local CE mean -> ce/(B*HW); global Dice -> * world
+        ctx.meta = (w_ce / float(B * HW), w_dice / ncls * world)
+        loss = out[0].clone()
+        ctx.mark_non_differentiable(out)
+        return loss, out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloss, _gout):
+        logits, labels, coef = ctx.saved_tensors
+        ce_scale, dice_scale = ctx.meta
+        B, ncls = logits.shape[:2]
+        HW = logits.numel() // (B * ncls)
+        gloss = dev_f32(gloss.reshape(1))
+        dlogits = torch.empty_like(logits)
+        call("cswin_loss_bwd", ptr(logits), ptr(labels), ptr(coef), ptr(gloss), ptr(dlogits), ce_scale, dice_scale, B, ncls,
+             HW, stream())
+        return dlogits, None, None, None, None
+
+
+def ce_dice_loss(logits, labels, w_ce=0.4, w_dice=0.6, group=None):
+    """0.4*CE + 0.6*Dice (trainer.py:55-57).  Returns (loss, stats) with stats = [loss, ce, dice] (no host sync).
+    With a process group the 1+3*ncls Dice/CE sums are all-reduced so Dice is the global-batch Dice."""
+    return _CeDiceLoss.apply(logits, labels, float(w_ce), float(w_dice), group)

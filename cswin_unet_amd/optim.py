@@ -1,0 +1,92 @@
+"""SGD(momentum, weight_decay) of the reference's training loop (trainer.py:42,60-63) on flat buffers.
+
+All parameters are re-pointed into ONE flat fp32 buffer (16-B aligned slots), momentum and gradients
+live in two more.  A step is two launches: a multi-tensor gather of the per-parameter .grad tensors
+into the flat gradient buffer (the buffer RCCL all-reduces, in buckets, under data parallelism) and
+one fused update kernel.  The learning rate lives in device memory so that a captured hipGraph can be
+replayed under the poly schedule.
+"""
+import numpy as np
+import torch
+
+from ._lib import call, ptr, stream
+
+_CHUNK = 16384      # floats per gather workgroup
+
+
+class FlatSGD:
+    def __init__(self, params, lr, momentum=0.9, weight_decay=1e-4):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatSGD got no trainable parameters")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatSGD runs on a HIP device only")
+        self.momentum, self.weight_decay = float(momentum), float(weight_decay)
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        self.numel = off
+        self.flat_param = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_mom = torch.zeros(off, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                view = self.flat_param[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view                       # parameters now alias the flat buffer
+        self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
+        self.lr = float(lr)
+        self._table, self._table_key = None, None
+        self.param_groups = [{"lr": self.lr, "params": self.params}]   # torch.optim-like view for loops that poke lr
+
+    # -- schedule -------------------------------------------------------------------------------------------
+    def set_lr(self, lr):
+        self.lr = float(lr)
+        self.param_groups[0]["lr"] = self.lr
+        self.lr_dev.fill_(self.lr)
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            p.grad = None
+
+    # -- step -----------------------------------------------------------------------------------------------
+    def _gather_table(self):
+        key = tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in self.params)
+        if key != self._table_key:
+            rows = []
+            base = self.flat_grad.data_ptr()
+            for p, o, src in zip(self.params, self.offsets, key):
+                if src == 0:
+                    raise RuntimeError("FlatSGD.step(): a parameter has no gradient")
+                if not p.grad.is_contiguous():
+                    raise RuntimeError("FlatSGD.step(): non-contiguous gradient")
+                n = p.numel()
+                for c in range(0, n, _CHUNK):
+                    rows.append((src + 4 * c, base + 4 * (o + c), min(_CHUNK, n - c)))
+            self._table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(self.flat_grad.device)
+            self._table_key = key
+        return self._table
+
+    def gather_grads(self):
+        """Pack every p.grad into self.flat_grad (one launch)."""
+        t = self._gather_table()
+        call("cswin_multi_copy", ptr(t), t.shape[0], stream())
+        return self.flat_grad
+
+    def apply(self, grad_scale=1.0):
+        """p, m <- SGD(flat_grad * grad_scale) (one launch)."""
+        call("cswin_sgd_flat", ptr(self.flat_param), ptr(self.flat_grad), ptr(self.flat_mom), self.numel, ptr(self.lr_dev),
+             self.momentum, self.weight_decay, float(grad_scale), stream())
+
+    def step(self, grad_scale=1.0):
+        self.gather_grads()
+        self.apply(grad_scale)
+
+    def state_dict(self):
+        return {"momentum": self.flat_mom.clone(), "lr": self.lr}
+
+    def load_state_dict(self, sd):
+        self.flat_mom.copy_(sd["momentum"])
+        self.set_lr(sd["lr"])

@@ -1,0 +1,142 @@
+/* libcswin_hip -- C ABI of the MI355X-native (gfx950) CSWin-UNet hot path.
+ *
+ * The reference (BoloniniD/CSWin-UNet) has no FFI of its own: its seam is the nn.Module surface
+ * of networks/cswin_unet.py.  Each entry point below replaces the device work behind one piece of
+ * that surface (reference file:line cited per function); cswin_unet_amd/_lib.py binds them with
+ * ctypes and cswin_unet_amd/networks/cswin_unet.py calls them from modules that keep the
+ * reference's class names, constructor signatures and state_dict keys.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (PyTorch's caching allocator in practice), fp32 unless stated, densely packed row-major.
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*), never synchronise, never
+ *     allocate, keep no pointer past return; entry points are re-entrant (no global mutable state
+ *     except the thread-local error string) and hipGraph-capturable.
+ *   - return 0 on success, a negative CSWIN_ERR_* code otherwise; cswin_last_error() gives the
+ *     message for the calling thread.  No exceptions, no exit() (the reference print+exit(0)s on a
+ *     bad stripe mode, cswin_unet.py:50-51; here that is CSWIN_ERR_SHAPE).
+ *   - "tokens" = the (B, L, C) layout the reference keeps between blocks; L = H*W row-major.
+ */
+#ifndef CSWIN_HIP_H
+#define CSWIN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSWIN_OK 0
+#define CSWIN_ERR_SHAPE (-1)
+#define CSWIN_ERR_ALIGN (-2)
+#define CSWIN_ERR_WORKSPACE (-3)
+#define CSWIN_ERR_HIP (-4)
+#define CSWIN_ERR_UNSUPPORTED (-5)
+
+const char* cswin_last_error(void);
+int cswin_abi_version(void);
+int cswin_device_ok(void); /* 1 if the current HIP device is gfx950 */
+
+/* ---- LePEAttention (cswin_unet.py:31-109), both branches of a CSWinBlock in one launch (:171-176) ----
+ * qkv (B, L, 3C) = output of the qkv Linear, channel layout [q | k | v] (:169).
+ * nbranch = 2: branch i works on channels [i*C/2, (i+1)*C/2) of each of q,k,v with stripe mode idx[i]
+ *   (0: H_sp=reso, W_sp=split; 1: H_sp=split, W_sp=reso; :43-48) and heads[i] heads;
+ * nbranch = 1: whole C, idx[0] = -1 (window = whole map).  Head dim must be 32.
+ * lepe_w[i] (Cb, 9) / lepe_b[i] (Cb) = get_v depthwise 3x3 weight/bias of branch i (:55).
+ * y (B, L, C): x = softmax(scale q k^T) v + lepe, scattered by windows2img and concatenated (:98-107, :174).
+ * lse (B, sum(heads), L): row log-sum-exp saved for backward.  scale <= 0 selects head_dim^-0.5 (:42). */
+int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, float* y, float* lse,
+                   int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split, float scale,
+                   void* stream);
+size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split);
+/* autograd backward of the above: dqkv (B, L, 3C), dlepe_w[i] (Cb, 9), dlepe_b[i] (Cb) are overwritten. */
+int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* lse, const float* dy, float* dqkv,
+                   float* const* dlepe_w, float* const* dlepe_b, void* workspace, size_t ws_bytes, int B, int reso,
+                   int C, int nbranch, const int* heads, const int* idx, int split, float scale, void* stream);
+
+/* ---- img2windows / windows2img (cswin_unet.py:184-202): index-only, bit-exact ----
+ * img (B, C, H, W) -> out (B*nH*nW, H_sp*W_sp, C);   win (B*nH*nW, H_sp*W_sp, C) -> out (B, H, W, C) */
+int cswin_img2windows(const float* img, float* out, int B, int C, int H, int W, int H_sp, int W_sp, void* stream);
+int cswin_windows2img(const float* win, float* out, int B, int C, int H, int W, int H_sp, int W_sp, void* stream);
+
+/* ---- nn.LayerNorm over C (cswin_unet.py:168,179,218,341,497,533); C in {32,64,128,256,512,1024} ---- */
+int cswin_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                        int M, int C, float eps, void* stream);
+size_t cswin_layernorm_bwd_workspace(int M, int C);
+/* dx = dres (optional residual-path gradient, may alias dx) + LN backward; dgamma/dbeta overwritten */
+int cswin_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                        const float* dres, float* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes,
+                        int M, int C, void* stream);
+
+/* ---- nn.Linear family: qkv / proj / Mlp.fc1+GELU / fc2 (cswin_unet.py:125,134,17-27), concat_linear{4,3,2}
+ *      (:404,417,428 with the torch.cat of :509,518,526 fused as a two-source K loop), 1x1 convs of CARAFE ----
+ * acc = [x | x2] (M, K) @ w (N, K)^T + bias.
+ *   y_act != NULL : y = acc (pre-activation), y_act = GELU_erf(acc)
+ *   residual != NULL : y = residual + row_scale[m / rows_per_sample] * acc     (x + drop_path(f(x)), :178-179)
+ * x2 == NULL: single source.  row_scale may be NULL (= 1). */
+int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* w, const float* bias, float* y,
+                     float* y_act, const float* residual, const float* row_scale, int rows_per_sample, int M, int N,
+                     int K, void* stream);
+/* dx (M, K) = add + row_scale * ((dy (M, N) @ w (N, K)) * gelu'(gelu_pre));  columns >= k_split go to dx2 if given */
+int cswin_linear_bwd_data(const float* dy, const float* w, float* dx, float* dx2, int k_split, const float* gelu_pre,
+                          const float* row_scale, int rows_per_sample, const float* add, int M, int N, int K,
+                          void* stream);
+size_t cswin_linear_bwd_weight_workspace(int M, int N, int K);
+/* dw (N, K) = (row_scale * dy)^T @ [x | x2];  dbias (N) = column sums (may be NULL) */
+int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, int k_split, const float* row_scale,
+                            int rows_per_sample, float* dw, float* dbias, void* workspace, size_t ws_bytes, int M,
+                            int N, int K, void* stream);
+
+/* ---- convolutions on tokens (NHWC) as implicit GEMM: stage1_conv_embed 7x7 s4 p2 (cswin_unet.py:339),
+ *      Merge_Block 3x3 s2 p1 (:208,214-217), CARAFE encoder 3x3 s1 p1 (:228-229,241) ----
+ * x (B, H*W, Cin) -> y (B, OH*OW, Cout).  Weights are given in the implicit-GEMM images made by
+ * cswin_conv_weight_permute from the nn.Conv2d parameter [Cout][Cin][ks][ks]. Cin % 4 == 0. */
+int cswin_conv_tok_fwd(const float* x, const float* w_perm, const float* bias, float* y, int B, int H, int W, int Cin,
+                       int Cout, int ks, int stride, int pad, void* stream);
+int cswin_conv_tok_bwd_data(const float* dy, const float* w_permT, float* dx, int B, int H, int W, int Cin, int Cout,
+                            int ks, int stride, int pad, void* stream);
+size_t cswin_conv_tok_bwd_weight_workspace(int B, int H, int W, int Cin, int Cout, int ks, int stride, int pad);
+int cswin_conv_tok_bwd_weight(const float* dy, const float* x, float* dw_perm, float* dbias, void* workspace,
+                              size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ks, int stride, int pad,
+                              void* stream);
+/* w [Cout][Cin][ks][ks] -> w_perm [Cout][ks*ks][Cpad] and/or w_permT [ks*ks][Cout][Cpad] (zero padded channels) */
+int cswin_conv_weight_permute(const float* w, float* w_perm, float* w_permT, int Cout, int Cin, int ks, int Cpad,
+                              void* stream);
+int cswin_conv_weight_unpermute(const float* dw_perm, float* dw, int Cout, int Cin, int ks, int Cpad, void* stream);
+
+/* ---- layout adapters at the ends of the token pipeline (Rearrange 'b c h w -> b (h w) c', cswin_unet.py:340;
+ *      view/permute of up_x4, :540-541) ---- */
+int cswin_nchw_to_tokens(const float* x, float* y, int B, int C, int H, int W, int Cpad, void* stream);
+int cswin_tokens_to_nchw(const float* x, float* y, int B, int C, int H, int W, int Cpad, void* stream);
+
+/* ---- CARAFE / CARAFE4 reassembly (cswin_unet.py:242-264, 292-314): softmax over the 9 taps + weighted
+ *      3x3 neighbourhood sum + pixel_shuffle, on tokens.  e (B, H*W, 9*S*S) = encoder output, channel
+ *      k*S*S + s;  z (B, H*W, Cz) = features to reassemble (the `out` 1x1 conv is applied BEFORE, at low
+ *      resolution: it commutes with the reassembly);  out (B, (S*H)*(S*W), Cz) = bias + reassembly. ---- */
+int cswin_carafe_fwd(const float* e, const float* z, const float* bias, float* out, float* wt_save, int B, int H,
+                     int W, int Cz, int S, void* stream);
+size_t cswin_carafe_bwd_workspace(int B, int H, int W, int Cz, int S);
+int cswin_carafe_bwd(const float* dout, const float* z, const float* wt_save, float* de, float* dz, float* dbias,
+                     void* workspace, size_t ws_bytes, int B, int H, int W, int Cz, int S, void* stream);
+
+/* ---- loss of the training step: 0.4*CE + 0.6*Dice (trainer.py:55-57, utils.py:9-45) ----
+ * logits (B, ncls, HW) fp32, labels (B, HW) int64.  sums[1 + 3*ncls] = {sum -log p[label], intersect_c, y_sum_c,
+ * z_sum_c}: all-reduce these across data-parallel ranks for the reference's global-batch Dice. */
+size_t cswin_loss_workspace(int B, int ncls, long HW);
+int cswin_loss_sums(const float* logits, const long long* labels, float* sums, void* workspace, size_t ws_bytes, int B,
+                    int ncls, long HW, void* stream);
+int cswin_loss_finalize(const float* sums, float* out3, float* coef, double n_pixels, int ncls, float w_ce,
+                        float w_dice, void* stream);
+int cswin_loss_bwd(const float* logits, const long long* labels, const float* coef, const float* grad_out,
+                   float* dlogits, float ce_scale, float dice_scale, int B, int ncls, long HW, void* stream);
+
+/* ---- optimiser: torch.optim.SGD(momentum, weight_decay) (trainer.py:42,60) on one flat buffer ---- */
+int cswin_sgd_flat(float* p, const float* g, float* m, long n, const float* lr_dev, float momentum,
+                   float weight_decay, float grad_scale, void* stream);
+/* table: device array of {const float* src; float* dst; long long n;} (24-byte records), one workgroup each */
+int cswin_multi_copy(const void* table, int nchunks, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSWIN_HIP_H */

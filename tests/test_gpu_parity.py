@@ -1,0 +1,384 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the C ABI, against
+ (a) the committed golden vectors generated from the imported reference (tests/golden), and
+ (b) the CPU oracle on the same seeded inputs at sizes the oracle finishes in seconds.
+Tolerance: 1e-3 relative (to tensor RMS) in fp32 as BASELINE.json's north_star states; the index-only
+ops are compared bit-exactly."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cswin_oracle as O
+from oracle.determ import det_labels, det_normal, fill_param, fill_state_dict, check_packed
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-3
+DEV = "cuda"
+LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_errors.log")
+
+
+def T(a, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t.requires_grad_() if grad else t
+
+
+def rel_err(got, ref, what):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    rms = float(ref.pow(2).mean().sqrt()) + 1e-30
+    err = float((got - ref).abs().max()) / rms
+    try:
+        os.makedirs(os.path.dirname(LOG), exist_ok=True)
+        with open(LOG, "a") as f:
+            f.write(f"{what}: {err:.3e}\n")
+    except OSError:
+        pass
+    assert np.isfinite(err) and err <= RTOL, f"{what}: max|diff|/rms = {err:.3e} > {RTOL}"
+    return err
+
+
+@pytest.fixture(scope="module")
+def N():
+    import cswin_unet_amd.networks.cswin_unet as net
+    return net
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from cswin_unet_amd import ops
+    return ops
+
+
+def test_library_is_the_hip_one():
+    from cswin_unet_amd import _lib
+    h = _lib.lib()
+    assert h.cswin_abi_version() == 1
+    assert h.cswin_device_ok() == 1, h.cswin_last_error().decode()
+    with pytest.raises(_lib.CswinHipError):         # no CPU fallback
+        from cswin_unet_amd import ops
+        ops.layer_norm(torch.zeros(4, 64), torch.ones(64), torch.zeros(64))
+
+
+ATTN = [(56, 0, 1, 32, 1), (56, 1, 1, 32, 1), (28, 0, 2, 64, 2), (28, 1, 2, 64, 2),
+        (14, 0, 7, 128, 4), (14, 1, 7, 128, 4), (7, -1, 7, 512, 16)]
+ATTN384 = [(96, 0, 1, 32, 1), (24, 0, 12, 128, 4), (24, 1, 12, 128, 4), (12, -1, 12, 512, 16)]
+
+
+@pytest.mark.parametrize("reso,idx,split,dim,heads", ATTN + ATTN384)
+def test_window_index_ops_bit_exact(N, golden, reso, idx, split, dim, heads):
+    g = golden("g1_index_maps")
+    key = f"r{reso}_i{idx}_s{split}"
+    H_sp, W_sp = O.window_shape(reso, idx, split)
+    C = 8
+    enc = (torch.arange(reso * reso, dtype=torch.float32)[:, None] * C + torch.arange(C, dtype=torch.float32)[None])
+    img = enc.t().reshape(1, C, reso, reso).repeat(2, 1, 1, 1)
+    img[1] += 0.5
+    win = N.img2windows(img.to(DEV), H_sp, W_sp)
+    gather = torch.from_numpy(g[key + ".gather"].astype(np.int64))                   # [nWin, N]
+    expect = enc[gather]                                                              # [nWin, N, C]
+    assert torch.equal(win.cpu(), torch.cat([expect, expect + 0.5]))
+    back = N.windows2img(win, H_sp, W_sp, reso, reso)
+    assert torch.equal(back.cpu(), img.permute(0, 2, 3, 1))
+    with pytest.raises(Exception):
+        N.img2windows(img.to(DEV), H_sp + 1, W_sp)
+
+
+@pytest.mark.parametrize("M,C", [(3136 * 2, 64), (784 * 3, 128), (197, 256), (49, 512), (5, 64), (1, 512)])
+def test_layernorm(ops, M, C):
+    x = det_normal(f"ln.x.{M}.{C}", (M, C)) * 2 + 0.3
+    g, b = 1 + 0.1 * det_normal("ln.g", (C,)), 0.1 * det_normal("ln.b", (C,))
+    dy = det_normal(f"ln.dy.{M}.{C}", (M, C))
+    xr, gr, br = (torch.from_numpy(a).requires_grad_() for a in (x, g, b))
+    yr = torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-5)
+    yr.backward(torch.from_numpy(dy))
+    xd, gd, bd = T(x, True), T(g, True), T(b, True)
+    yd = ops.layer_norm(xd, gd, bd, 1e-5)
+    yd.backward(T(dy))
+    rel_err(yd, yr, f"ln{M}x{C}.y")
+    rel_err(xd.grad, xr.grad, f"ln{M}x{C}.dx")
+    rel_err(gd.grad, gr.grad, f"ln{M}x{C}.dgamma")
+    rel_err(bd.grad, br.grad, f"ln{M}x{C}.dbeta")
+
+
+LIN = [(3136 * 2, 192, 64), (784 * 2, 384, 128), (392, 768, 256), (98, 1536, 512), (98, 2048, 512), (98, 512, 2048),
+       (1, 9, 64), (37, 36, 100), (300, 16, 64), (129, 65, 33)]
+
+
+@pytest.mark.parametrize("M,Nn,K", LIN)
+def test_linear_fwd_bwd(ops, M, Nn, K):
+    x, w, b = det_normal("lin.x", (M, K)), det_normal("lin.w", (Nn, K)) / np.sqrt(K), det_normal("lin.b", (Nn,))
+    dy = det_normal("lin.dy", (M, Nn))
+    xr, wr, br = (torch.from_numpy(a).requires_grad_() for a in (x, w, b))
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr.backward(torch.from_numpy(dy))
+    xd, wd, bd = T(x, True), T(w, True), T(b, True)
+    yd = ops.linear(xd, wd, bd)
+    yd.backward(T(dy))
+    tag = f"linear{M}x{Nn}x{K}"
+    rel_err(yd, yr, tag + ".y")
+    rel_err(xd.grad, xr.grad, tag + ".dx")
+    rel_err(wd.grad, wr.grad, tag + ".dw")
+    rel_err(bd.grad, br.grad, tag + ".db")
+
+
+def test_linear_concat_residual_droppath(ops):
+    B, L, C = 3, 196, 256
+    skip, x = det_normal("cl.skip", (B, L, C)), det_normal("cl.x", (B, L, C))
+    w, b = det_normal("cl.w", (C, 2 * C)) / np.sqrt(2 * C), det_normal("cl.b", (C,))
+    res, dy = det_normal("cl.res", (B, L, C)), det_normal("cl.dy", (B, L, C))
+    rs = np.array([0.0, 1.25, 1.25], np.float32)
+    ref = [torch.from_numpy(a).requires_grad_() for a in (skip, x, w, b, res)]
+    yr = ref[4] + torch.from_numpy(rs).view(-1, 1, 1) * torch.nn.functional.linear(torch.cat(ref[:2], -1), ref[2], ref[3])
+    yr.backward(torch.from_numpy(dy))
+    dev = [T(a, True) for a in (skip, x, w, b, res)]
+    yd = ops.linear(dev[0], dev[2], dev[3], x2=dev[1], residual=dev[4], row_scale=T(rs))
+    yd.backward(T(dy))
+    rel_err(yd, yr, "concat_linear.y")
+    for n, d, r in zip(("dskip", "dx", "dw", "db", "dres"), dev, ref):
+        rel_err(d.grad, r.grad, "concat_linear." + n)
+
+
+def test_mlp_fused(ops):
+    B, L, C = 2, 784, 128
+    x, res, dy = (det_normal("mlp." + n, (B, L, C)) for n in ("x", "res", "dy"))
+    w1, b1 = det_normal("mlp.w1", (4 * C, C)) / np.sqrt(C), 0.1 * det_normal("mlp.b1", (4 * C,))
+    w2, b2 = det_normal("mlp.w2", (C, 4 * C)) / np.sqrt(4 * C), 0.1 * det_normal("mlp.b2", (C,))
+    rs = np.array([1.1111, 0.0], np.float32)
+    ref = [torch.from_numpy(a).requires_grad_() for a in (x, w1, b1, w2, b2, res)]
+    F = torch.nn.functional
+    yr = ref[5] + torch.from_numpy(rs).view(-1, 1, 1) * F.linear(F.gelu(F.linear(ref[0], ref[1], ref[2])), ref[3], ref[4])
+    yr.backward(torch.from_numpy(dy))
+    dev = [T(a, True) for a in (x, w1, b1, w2, b2, res)]
+    yd = ops.mlp(*dev[:5], residual=dev[5], row_scale=T(rs))
+    yd.backward(T(dy))
+    rel_err(yd, yr, "mlp.y")
+    for n, d, r in zip(("dx", "dw1", "db1", "dw2", "db2", "dres"), dev, ref):
+        rel_err(d.grad, r.grad, "mlp." + n)
+
+
+@pytest.mark.parametrize("reso,idx,split,dim,heads", ATTN)
+def test_attention_vs_golden(N, golden, reso, idx, split, dim, heads):
+    g = golden("g2_attention")
+    key = f"r{reso}_i{idx}_s{split}"
+    L = reso * reso
+    att = N.LePEAttention(dim, resolution=reso, idx=idx, split_size=split, num_heads=heads).to(DEV)
+    fill_state_dict(att, prefix=f"attn.{key}.")
+    q, k, v = (T(det_normal(f"attn.{key}.{n}", (2, L, dim)), True) for n in "qkv")
+    y = att([q, k, v])
+    y.backward(T(det_normal(f"attn.{key}.dy", (2, L, dim))))
+    for name, t in [("y", y), ("dq", q.grad), ("dk", k.grad), ("dv", v.grad), ("dw", att.get_v.weight.grad),
+                    ("db", att.get_v.bias.grad)]:
+        err = check_packed(t, g, f"{key}.{name}.", RTOL, what="attention ")
+        with open(LOG, "a") as f:
+            f.write(f"attn_golden.{key}.{name}: {err:.3e}\n")
+
+
+@pytest.mark.parametrize("reso,idx,split,dim,heads", ATTN384)
+def test_attention_384_forward_vs_golden(N, golden, reso, idx, split, dim, heads):
+    g = golden("g2_attention")
+    key = f"r{reso}_i{idx}_s{split}"
+    L = reso * reso
+    att = N.LePEAttention(dim, resolution=reso, idx=idx, split_size=split, num_heads=heads).to(DEV)
+    fill_state_dict(att, prefix=f"attn.{key}.")
+    with torch.no_grad():
+        y = att([T(det_normal(f"attn.{key}.{n}", (2, L, dim))) for n in "qkv"])
+    check_packed(y, g, f"{key}.y.", RTOL, what="attention384 ")
+
+
+@pytest.mark.parametrize("dim,reso,heads,split,last", [(64, 56, 2, 1, False), (128, 28, 4, 2, False),
+                                                        (256, 14, 8, 7, False), (512, 7, 16, 7, True)])
+def test_block_vs_golden(N, golden, dim, reso, heads, split, last):
+    g = golden("g3_blocks")
+    key = f"c{dim}_r{reso}"
+    blk = N.CSWinBlock(dim=dim, reso=reso, num_heads=heads, split_size=split, mlp_ratio=4., qkv_bias=True,
+                       drop_path=0., last_stage=last).to(DEV)
+    fill_state_dict(blk, prefix=f"block.{key}.")
+    x = T(det_normal(f"block.{key}.x", (2, reso * reso, dim)), True)
+    y = blk(x)
+    y.backward(T(det_normal(f"block.{key}.dy", (2, reso * reso, dim))))
+    check_packed(y, g, f"{key}.y.", RTOL, what="block ")
+    check_packed(x.grad, g, f"{key}.dx.", RTOL, what="block ")
+    for n, p in blk.named_parameters():
+        err = check_packed(p.grad, g, f"{key}.grad.{n}.", RTOL, what=f"block {key} {n} ")
+        with open(LOG, "a") as f:
+            f.write(f"block_golden.{key}.{n}: {err:.3e}\n")
+
+
+def test_block_droppath_injected_mask(N, monkeypatch):
+    """DropPath parity with an injected per-sample mask (timm's RNG stream is unpinned)."""
+    dim, reso, heads, split = 128, 28, 4, 2
+    blk = N.CSWinBlock(dim=dim, reso=reso, num_heads=heads, split_size=split, qkv_bias=True, drop_path=0.25).to(DEV)
+    fill_state_dict(blk, prefix="block.c128_r28.")
+    blk.train()
+    scales = [np.array([0.0, 4 / 3, 4 / 3], np.float32), np.array([4 / 3, 0.0, 4 / 3], np.float32)]
+    it = iter(scales)
+    monkeypatch.setattr(blk.drop_path, "sample_scale", lambda b, dev: T(next(it)))
+    x = det_normal("dp.x", (3, reso * reso, dim))
+    dy = det_normal("dp.dy", (3, reso * reso, dim))
+    xd = T(x, True)
+    yd = blk(xd)
+    yd.backward(T(dy))
+    P = {"b." + n: p.detach().cpu().clone().requires_grad_() for n, p in blk.named_parameters()}
+    xr = torch.from_numpy(x).requires_grad_()
+
+    class TwoScales:                      # oracle applies one keep_scale to both branches; emulate two draws
+        pass
+    F = torch.nn.functional
+    h = F.layer_norm(xr, (dim,), P["b.norm1.weight"], P["b.norm1.bias"])
+    qkv = F.linear(h, P["b.qkv.weight"], P["b.qkv.bias"])
+    q, k, v = qkv.split(dim, -1)
+    parts = [O.lepe_attention(q[..., s], k[..., s], v[..., s], P[f"b.attns.{i}.get_v.weight"], P[f"b.attns.{i}.get_v.bias"],
+                              reso, i, split, heads // 2) for i, s in enumerate((slice(0, dim // 2), slice(dim // 2, dim)))]
+    x1 = xr + torch.from_numpy(scales[0]).view(-1, 1, 1) * F.linear(torch.cat(parts, 2), P["b.proj.weight"], P["b.proj.bias"])
+    h = F.layer_norm(x1, (dim,), P["b.norm2.weight"], P["b.norm2.bias"])
+    h = F.linear(F.gelu(F.linear(h, P["b.mlp.fc1.weight"], P["b.mlp.fc1.bias"])), P["b.mlp.fc2.weight"], P["b.mlp.fc2.bias"])
+    yr = x1 + torch.from_numpy(scales[1]).view(-1, 1, 1) * h
+    yr.backward(torch.from_numpy(dy))
+    rel_err(yd, yr, "droppath.y")
+    rel_err(xd.grad, xr.grad, "droppath.dx")
+    for n, p in blk.named_parameters():
+        rel_err(p.grad, P["b." + n].grad, "droppath.grad." + n)
+
+
+def test_patch_embed_vs_golden(N, golden):
+    g = golden("g4_convs")
+    stem = N._PatchEmbed(torch.nn.Conv2d(3, 64, 7, 4, 2), N.TokenRearrange(), torch.nn.LayerNorm(64)).to(DEV)
+    fill_state_dict(stem, prefix="stem.stage1_conv_embed.")
+    y = stem(T(det_normal("stem.x", (2, 3, 224, 224))))
+    y.backward(T(det_normal("stem.dy", (2, 3136, 64))))
+    check_packed(y, g, "stem.y.", RTOL)
+    for n, p in stem.named_parameters():
+        check_packed(p.grad, g, f"stem.grad.{n}.", RTOL, what=n + " ")
+
+
+def _run_module_vs_golden(mod, key, in_shape, out_shape, g):
+    mod = mod.to(DEV)
+    fill_state_dict(mod, prefix=key + ".")
+    x = T(det_normal(key + ".x", in_shape), True)
+    y = mod(x)
+    assert tuple(y.shape) == tuple(out_shape)
+    y.backward(T(det_normal(key + ".dy", out_shape)))
+    errs = {"y": check_packed(y, g, key + ".y.", RTOL, what=key + " "),
+            "dx": check_packed(x.grad, g, key + ".dx.", RTOL, what=key + " ")}
+    for n, p in mod.named_parameters():
+        errs[n] = check_packed(p.grad, g, f"{key}.grad.{n}.", RTOL, what=f"{key} {n} ")
+    with open(LOG, "a") as f:
+        for n, e in errs.items():
+            f.write(f"{key}.{n}: {e:.3e}\n")
+
+
+@pytest.mark.parametrize("i,c,r", [(1, 64, 56), (2, 128, 28), (3, 256, 14)])
+def test_merge_vs_golden(N, golden, i, c, r):
+    _run_module_vs_golden(N.Merge_Block(c, 2 * c), f"merge{i}", (2, r * r, c), (2, r * r // 4, 2 * c), golden("g4_convs"))
+
+
+@pytest.mark.parametrize("name,c,cout,r,S,B", [("upsample4", 512, 256, 7, 2, 2), ("upsample3", 256, 128, 14, 2, 2),
+                                               ("upsample2", 128, 64, 28, 2, 2), ("upsample1", 64, 64, 56, 4, 2),
+                                               ("carafe4_small", 16, 8, 5, 4, 1), ("carafe2_small", 16, 8, 6, 2, 1)])
+def test_carafe_vs_golden(N, golden, name, c, cout, r, S, B):
+    mod = N.CARAFE(c, cout) if S == 2 else N.CARAFE4(c, cout)
+    _run_module_vs_golden(mod, name, (B, r * r, c), (B, S * S * r * r, cout), golden("g4_convs"))
+
+
+def test_loss_vs_oracle(ops):
+    B, C, H = 3, 9, 64
+    logits = 2 * det_normal("loss.logits", (B, C, H, H))
+    lab = det_labels("loss.lab", (B, H, H), C)
+    lr = torch.from_numpy(logits).requires_grad_()
+    loss_r, ce_r, dice_r = O.ce_dice_loss(lr, torch.from_numpy(lab), C)
+    (loss_r * 1.7).backward()
+    ld = T(logits, True)
+    loss_d, stats = ops.ce_dice_loss(ld, T(lab))
+    (loss_d * 1.7).backward()
+    assert abs(float(loss_d) - float(loss_r)) < 1e-4 * abs(float(loss_r))
+    assert abs(float(stats[1]) - float(ce_r)) < 1e-4 and abs(float(stats[2]) - float(dice_r)) < 1e-4
+    rel_err(ld.grad, lr.grad, "loss.dlogits")
+
+
+def _golden_model(N, drop_path=0.):
+    net = N.CSWinTransformer(img_size=224, num_classes=9, embed_dim=64, depth=[1, 2, 9, 1], split_size=[1, 2, 7, 7],
+                             num_heads=[2, 4, 8, 16], mlp_ratio=4., qkv_bias=True, drop_path_rate=drop_path).to(DEV)
+    return fill_state_dict(net)
+
+
+def test_full_model_vs_golden(N, ops, golden):
+    g = golden("g5_model")
+    from cswin_unet_amd.optim import FlatSGD
+    net = _golden_model(N)
+    net.train()
+    img = T(det_normal("model.x", (2, 1, 224, 224))).repeat(1, 3, 1, 1)
+    lab = T(det_labels("model.labels", (2, 224, 224), 9))
+    opt = FlatSGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    losses = []
+    for it in range(3):
+        logits = net(img)
+        loss, stats = ops.ce_dice_loss(logits, lab)
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            check_packed(logits, g, "logits.", RTOL, what="model ")
+            assert abs(float(stats[1]) - float(g["loss_ce"])) < 1e-3 * float(g["loss_ce"])
+            assert abs(float(stats[2]) - float(g["loss_dice"])) < 1e-3 * float(g["loss_dice"])
+            params = dict(net.named_parameters())
+            with open(LOG, "a") as f:
+                for m in [k[len("gradnorm."):] for k in g.files if k.startswith("gradnorm.")]:
+                    sq = sum(float((p.grad.double() ** 2).sum()) for n, p in params.items() if n.startswith(m + "."))
+                    ref = float(g["gradnorm." + m])
+                    f.write(f"model.gradnorm.{m}: {abs(np.sqrt(sq) - ref) / ref:.3e}\n")
+                    assert abs(np.sqrt(sq) - ref) <= RTOL * ref, (m, np.sqrt(sq), ref)
+            for k in sorted({k[len("grad."):].rsplit(".", 1)[0] for k in g.files if k.startswith("grad.")}):
+                check_packed(params[k].grad, g, f"grad.{k}.", RTOL, what=k + " ")
+        opt.step()
+        opt.set_lr(O.poly_lr(0.05, it, 100))              # trainer.py:61-63: schedule applied after the step
+        losses.append(float(loss))
+    assert np.allclose(losses, g["sgd_losses"], rtol=2e-3), (losses, g["sgd_losses"])
+    chk = sum(float(p.detach().double().abs().sum()) for p in net.parameters())
+    assert abs(chk - float(g["sgd_weight_checksum"])) <= 1e-4 * float(g["sgd_weight_checksum"])
+
+
+def test_eval_argmax_vs_golden(N, golden):
+    g = golden("g6_eval")
+    net = _golden_model(N).eval()
+    with torch.no_grad():
+        logits = net(T(det_normal("model.x", (2, 1, 224, 224))).repeat(1, 3, 1, 1))
+    check_packed(logits, g, "logits.", RTOL, what="eval ")
+    agree = (logits.argmax(1).cpu().numpy().astype(np.uint8) == g["argmax"]).mean()
+    assert agree >= 0.999, agree            # "Dice vs ref": identical segmentation map
+
+
+def test_model_384_forward_vs_golden(N, golden):
+    net = N.CSWinTransformer(img_size=384, num_classes=9, embed_dim=64, depth=[1, 2, 9, 1], split_size=[1, 2, 12, 12],
+                             num_heads=[2, 4, 8, 16], qkv_bias=True).to(DEV)
+    fill_state_dict(net).eval()
+    with torch.no_grad():
+        logits = net(T(det_normal("model384.x", (1, 3, 384, 384))))
+    check_packed(logits, golden("g7_model384"), "logits.", RTOL, what="model384 ")
+
+
+def test_full_size_properties(N, ops):
+    """BASELINE sizes (B=24): size-independent properties instead of an oracle run.
+    * attention is linear in V (and in the LePE bias-free part): f(q,k,a v1 + b v2) = a f(v1) + b f(v2) with bias 0
+    * softmax rows sum to one: with V = const and LePE = 0 the output is that constant
+    * img2windows -> windows2img is the identity (bit-exact)."""
+    B, reso, dim, heads, split = 24, 14, 256, 8, 7
+    L = reso * reso
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    qkv1 = torch.randn(B, L, 3 * dim, generator=g).to(DEV)
+    qkv2 = qkv1.clone()
+    qkv2[..., 2 * dim:] = torch.randn(B, L, dim, generator=g).to(DEV)
+    w = [torch.randn(dim // 2, 1, 3, 3, generator=g).to(DEV) for _ in range(2)]
+    zb = [torch.zeros(dim // 2, device=DEV) for _ in range(2)]
+    f = lambda t: ops.stripe_attention(t, reso, split, [0, 1], [heads // 2] * 2, w, zb)
+    mix = qkv1.clone()
+    mix[..., 2 * dim:] = 0.75 * qkv1[..., 2 * dim:] - 1.5 * qkv2[..., 2 * dim:]
+    rel_err(f(mix), 0.75 * f(qkv1) - 1.5 * f(qkv2), "prop.attn_linear_in_v")
+    const = qkv1.clone()
+    const[..., 2 * dim:] = 3.25
+    zw = [torch.zeros_like(t) for t in w]
+    out = ops.stripe_attention(const, reso, split, [0, 1], [heads // 2] * 2, zw, zb)
+    rel_err(out, torch.full_like(out, 3.25), "prop.softmax_rows_sum_to_one")
+    img = torch.randn(B, 64, 56, 56, generator=g).to(DEV)
+    for hs, ws in ((56, 1), (1, 56), (7, 7)):
+        assert torch.equal(N.windows2img(N.img2windows(img, hs, ws), hs, ws, 56, 56), img.permute(0, 2, 3, 1))
