@@ -82,13 +82,13 @@ def test_window_index_ops_bit_exact(N, golden, reso, idx, split, dim, heads):
     back = N.windows2img(win, H_sp, W_sp, reso, reso)
     assert torch.equal(back.cpu(), img.permute(0, 2, 3, 1))
     with pytest.raises(Exception):
-        N.img2windows(img.to(DEV), H_sp + 1, W_sp)
+        N.img2windows(img.to(DEV), 5, W_sp)
 
 
 @pytest.mark.parametrize("M,C", [(3136 * 2, 64), (784 * 3, 128), (197, 256), (49, 512), (5, 64), (1, 512)])
 def test_layernorm(ops, M, C):
-    x = det_normal(f"ln.x.{M}.{C}", (M, C)) * 2 + 0.3
-    g, b = 1 + 0.1 * det_normal("ln.g", (C,)), 0.1 * det_normal("ln.b", (C,))
+    x = (det_normal(f"ln.x.{M}.{C}", (M, C), 2.0) + 0.3).astype(np.float32)
+    g, b = (1 + det_normal("ln.g", (C,), 0.1)).astype(np.float32), det_normal("ln.b", (C,), 0.1)
     dy = det_normal(f"ln.dy.{M}.{C}", (M, C))
     xr, gr, br = (torch.from_numpy(a).requires_grad_() for a in (x, g, b))
     yr = torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-5)
@@ -108,7 +108,7 @@ LIN = [(3136 * 2, 192, 64), (784 * 2, 384, 128), (392, 768, 256), (98, 1536, 512
 
 @pytest.mark.parametrize("M,Nn,K", LIN)
 def test_linear_fwd_bwd(ops, M, Nn, K):
-    x, w, b = det_normal("lin.x", (M, K)), det_normal("lin.w", (Nn, K)) / np.sqrt(K), det_normal("lin.b", (Nn,))
+    x, w, b = det_normal("lin.x", (M, K)), det_normal("lin.w", (Nn, K), 1 / np.sqrt(K)), det_normal("lin.b", (Nn,))
     dy = det_normal("lin.dy", (M, Nn))
     xr, wr, br = (torch.from_numpy(a).requires_grad_() for a in (x, w, b))
     yr = torch.nn.functional.linear(xr, wr, br)
@@ -126,7 +126,7 @@ def test_linear_fwd_bwd(ops, M, Nn, K):
 def test_linear_concat_residual_droppath(ops):
     B, L, C = 3, 196, 256
     skip, x = det_normal("cl.skip", (B, L, C)), det_normal("cl.x", (B, L, C))
-    w, b = det_normal("cl.w", (C, 2 * C)) / np.sqrt(2 * C), det_normal("cl.b", (C,))
+    w, b = det_normal("cl.w", (C, 2 * C), 1 / np.sqrt(2 * C)), det_normal("cl.b", (C,))
     res, dy = det_normal("cl.res", (B, L, C)), det_normal("cl.dy", (B, L, C))
     rs = np.array([0.0, 1.25, 1.25], np.float32)
     ref = [torch.from_numpy(a).requires_grad_() for a in (skip, x, w, b, res)]
@@ -143,8 +143,8 @@ def test_linear_concat_residual_droppath(ops):
 def test_mlp_fused(ops):
     B, L, C = 2, 784, 128
     x, res, dy = (det_normal("mlp." + n, (B, L, C)) for n in ("x", "res", "dy"))
-    w1, b1 = det_normal("mlp.w1", (4 * C, C)) / np.sqrt(C), 0.1 * det_normal("mlp.b1", (4 * C,))
-    w2, b2 = det_normal("mlp.w2", (C, 4 * C)) / np.sqrt(4 * C), 0.1 * det_normal("mlp.b2", (C,))
+    w1, b1 = det_normal("mlp.w1", (4 * C, C), 1 / np.sqrt(C)), det_normal("mlp.b1", (4 * C,), 0.1)
+    w2, b2 = det_normal("mlp.w2", (C, 4 * C), 1 / np.sqrt(4 * C)), det_normal("mlp.b2", (C,), 0.1)
     rs = np.array([1.1111, 0.0], np.float32)
     ref = [torch.from_numpy(a).requires_grad_() for a in (x, w1, b1, w2, b2, res)]
     F = torch.nn.functional
@@ -284,7 +284,7 @@ def test_carafe_vs_golden(N, golden, name, c, cout, r, S, B):
 
 def test_loss_vs_oracle(ops):
     B, C, H = 3, 9, 64
-    logits = 2 * det_normal("loss.logits", (B, C, H, H))
+    logits = det_normal("loss.logits", (B, C, H, H), 2.0)
     lab = det_labels("loss.lab", (B, H, H), C)
     lr = torch.from_numpy(logits).requires_grad_()
     loss_r, ce_r, dice_r = O.ce_dice_loss(lr, torch.from_numpy(lab), C)
