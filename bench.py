@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CSWin-UNet (cswin_tiny_224_lite) training images/sec on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = forward -> 0.4*CE + 0.6*Dice -> backward (-> RCCL all-reduce) -> SGD(momentum) update on a synthetic
+224x224 9-class minibatch of 24 images per GPU (BASELINE.json configs[1]; weak scaling), fp32, inputs resident in HBM.
+Rank 0 prints ONE JSON line.  At N=1 it also carries
+  * "roofline": the stripe-attention kernels (the kernels north_star names), timed live with HIP events on the launch
+    stream, algorithmic FLOPs from SURVEY.md 8(d): 4*L*N*C per block per image forward, x2 more for backward;
+  * "cpu_baseline": the CPU oracle's identical training step timed on this host's cores (kind "port").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_HBM_GBPS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def attention_roofline(batch, cfg, reps=20):
+    """Times attn fwd / bwd for the four stage shapes of the model at this batch.  Returns the roofline object."""
+    from cswin_unet_amd import ops
+    dev = "cuda"
+    E, depth, heads, split = cfg.EMBED_DIM, cfg.DEPTH, cfg.NUM_HEADS, cfg.SPLIT_SIZE
+    reso0 = 224 // 4
+    rows, tot_flops, tot_time, tot_bytes = [], 0.0, 0.0, 0.0
+    g = torch.Generator(device="cpu").manual_seed(7)
+    for si in range(4):
+        C, reso = E << si, reso0 >> si
+        L = reso * reso
+        single = si == 3 or reso == split[si]
+        idx = [-1] if single else [0, 1]
+        hb = [heads[si]] if single else [heads[si] // 2] * 2
+        cb = C // len(idx)
+        n_win = reso * reso if single else reso * split[si]
+        qkv = torch.randn(batch, L, 3 * C, generator=g).to(dev).requires_grad_()
+        w = [(torch.randn(cb, 1, 3, 3, generator=g) / 3).to(dev).requires_grad_() for _ in idx]
+        b = [(torch.randn(cb, generator=g) * 0.02).to(dev).requires_grad_() for _ in idx]
+        dy = torch.randn(batch, L, C, generator=g).to(dev)
+        fwd = lambda: ops.stripe_attention(qkv, reso, split[si], idx, hb, w, b)
+
+        def timed(fn):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e-3 / reps
+
+        with torch.no_grad():
+            t_f = timed(fwd)
+        y = fwd()
+
+        def bwd():
+            qkv.grad = None
+            y.backward(dy, retain_graph=True)
+        t_fb = timed(bwd)                       # backward only (forward output retained): attn_bwd + lepe reduce
+        flops_f = 4.0 * L * n_win * C * batch    # QK^T + PV, 2*MAC
+        n_blocks = 2 * depth[si]
+        bytes_f = 16.0 * L * C * batch           # read q,k,v + write y (fp32)
+        rows.append({"stage": si + 1, "window_tokens": n_win, "launches_per_step": n_blocks,
+                     "fwd_us": round(t_f * 1e6, 2), "bwd_us": round(t_fb * 1e6, 2),
+                     "fwd_tflops": round(flops_f / t_f / 1e12, 2), "bwd_tflops": round(2 * flops_f / t_fb / 1e12, 2),
+                     "fwd_hbm_gbps": round(bytes_f / t_f / 1e9, 1)})
+        tot_flops += n_blocks * 3.0 * flops_f
+        tot_time += n_blocks * (t_f + t_fb)
+        tot_bytes += n_blocks * 3.0 * bytes_f
+    achieved = tot_flops / tot_time / 1e12
+    return {"kernel": "attn_fwd_kernel + attn_bwd_kernel (all 26 blocks, fwd+bwd)", "bound": "mfma",
+            "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
+            "algorithmic_gflop_per_step": round(tot_flops / 1e9, 2), "time_per_step_ms": round(tot_time * 1e3, 3),
+            "hbm_frac_algorithmic": round(tot_bytes / tot_time / 1e9 / PEAK_HBM_GBPS, 4), "per_stage": rows}
+
+
+def cpu_baseline(batch, steps=2):
+    """The CPU oracle's training step (same model, loss, optimiser, synthetic batch) on the host cores."""
+    from oracle import cswin_oracle as O
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(1234)
+    P = O.golden_params()
+    img = torch.randn(batch, 1, 224, 224, generator=g)
+    lab = torch.randint(0, 9, (batch, 224, 224), generator=g)
+    M = {}
+    O.train_step(P, M, img, lab, 0.05)          # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.train_step(P, M, img, lab, 0.05)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(batch / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{steps} timed training steps (+1 warm-up) of batch {batch}, cswin_tiny_224_lite fp32, "
+                      f"torch-CPU oracle (oracle/cswin_oracle.py)", "ms_per_step": round(dt * 1e3, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=24, help="images per GPU")
+    ap.add_argument("--cfg", default=os.path.join(ROOT, "configs", "cswin_tiny_224_lite.yaml"))
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying hipGraphs")
+    ap.add_argument("--skip-roofline", action="store_true")
+    ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=24)
+    args = ap.parse_args()
+
+    from cswin_unet_amd.config import get_config
+    from cswin_unet_amd.networks.vision_transformer import CSwinUnet
+    from cswin_unet_amd.trainer import DataParallelTrainer, init_distributed, synthetic_batch
+
+    rank, local, world, group = init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path)"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    config = get_config(args.cfg)
+    num_classes = 9
+    torch.manual_seed(1234)
+    model = CSwinUnet(config, img_size=config.DATA.IMG_SIZE, num_classes=num_classes).to(dev)
+    model.train()
+    total_steps = args.warmup + args.steps + 8
+    trainer = DataParallelTrainer(model, num_classes, base_lr=0.05, max_iterations=max(total_steps, 1000), group=group,
+                                  use_graph=not args.no_graph)
+    img, lab = synthetic_batch(args.batch, config.DATA.IMG_SIZE, num_classes, 1234 + rank, dev)
+
+    for _ in range(2):                      # set-up steps (eager warm-up + hipGraph capture happen in the first), not part of W
+        trainer.train_step(img, lab)
+    for _ in range(args.warmup):
+        trainer.train_step(img, lab)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats = trainer.train_step(img, lab)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = [float(v) for v in stats.tolist()]
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {"metric": "training images/sec (224x224, cswin_tiny)", "value": round(world * args.batch * args.steps / elapsed, 2),
+               "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "cswin_tiny_224_lite, synthetic 224x224 9-class, bs=24/GPU, fp32, "
+                                      "fwd + 0.4CE+0.6Dice + bwd + SGD(momentum) step, drop_path 0.2",
+                          "global_batch": world * args.batch, "img_size": config.DATA.IMG_SIZE,
+                          "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+               "final_loss": {"loss": round(loss[0], 5), "ce": round(loss[1], 5), "dice": round(loss[2], 5)},
+               "model_tflops": round(33.2e9 * world * args.batch * args.steps / elapsed / 1e12, 2)}
+        if world == 1 and not args.skip_roofline:
+            out["roofline"] = attention_roofline(args.batch, config.MODEL.CSWIN)
+        if world == 1 and not args.skip_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -506,9 +506,11 @@ template <int NT>
 int launch_fwd(const AttnParams& p, int nwg, hipStream_t st) {
     constexpr int NW = NT < 8 ? NT : 8;
     const size_t lds = (size_t)(2 * 16 * NT * LDT + 10 * HD) * sizeof(float);
-    if (lds > 64 * 1024) {
+    static bool reserved = false;       // one-time, idempotent: not a stream operation, keep it out of graph captures
+    if (lds > 64 * 1024 && !reserved) {
         hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { cswin_set_error("attn_fwd: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return CSWIN_ERR_HIP; }
+        reserved = true;
     }
     hipLaunchKernelGGL((attn_fwd_kernel<NT>), dim3(nwg), dim3(64 * NW), lds, st, p);
     return CSWIN_OK;
@@ -522,9 +524,11 @@ size_t bwd_lds_bytes() {
 template <int NT>
 int launch_bwd(const AttnParams& p, int nwg, hipStream_t st) {
     const size_t lds = bwd_lds_bytes<NT>();
-    if (lds > 64 * 1024) {
+    static bool reserved = false;
+    if (lds > 64 * 1024 && !reserved) {
         hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { cswin_set_error("attn_bwd: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return CSWIN_ERR_HIP; }
+        reserved = true;
     }
     hipLaunchKernelGGL((attn_bwd_kernel<NT>), dim3(nwg), dim3(64 * NT), lds, st, p);
     return CSWIN_OK;

@@ -172,14 +172,6 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     }
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int C, int nblk) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(long)b * C + c];
-    out[c] = s;
-}
-
 int colsum_blocks(long rows, int C) {
     int lanes = C < 256 ? C : 256;
     int rg = 256 / lanes;
@@ -240,7 +232,7 @@ int cswin_carafe_bwd(const float* dout, const float* z, const float* wt_save, fl
     if (dbias) {
         int nblk = colsum_blocks(items, Cz);
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, dout, (float*)workspace, items, Cz);
-        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(Cz, 256)), dim3(256), 0, st, (const float*)workspace, dbias, Cz, nblk);
+        launch_rows_sum((const float*)workspace, dbias, nullptr, 0, Cz, nblk, Cz, st);
         CSWIN_LAUNCH_CHECK();
     }
     return CSWIN_OK;

@@ -18,12 +18,13 @@
 // image with conflict-free ds_read_b32.  Global loads are 16 B per lane; LDS is single
 // buffered with register prefetch of the next tile (4 workgroups of 4 waves co-reside per CU
 // and cover each other's barriers).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
-constexpr int BK = 32;        // reduction tile
-constexpr int LDR = BK + 4;   // [row][r] image: 144-B rows -> conflict-free b128 reads
+constexpr int BKMAX = 64;     // largest reduction tile (split sizes are multiples of it)
 
 // ------------------------------------------------------------------------------------
 // operand sources: a logical matrix S(i, j) whose fast (contiguous) index is j
@@ -114,66 +115,150 @@ struct ConvTSrc {
 // ------------------------------------------------------------------------------------
 // epilogue
 // ------------------------------------------------------------------------------------
+enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_RES = 2, EPI_GELUBWD = 3, EPI_SPLIT2 = 4 };
+
 struct Epilogue {
     float* C; long ldc;
-    float* C2; long ldc2; int col_split;      // columns >= col_split are written to C2[m][n - col_split]
-    const float* bias;                        // [N]
-    float* Cact; long ldact;                  // gelu(acc + bias) second output (C keeps the pre-activation)
-    const float* residual; long ldres;        // C = residual + row_scale * (acc + bias)
-    const float* row_scale; int rows_per_sample;
-    const float* gelu_pre; long ldpre;        // C = acc * gelu'(gelu_pre[m][n])
+    float* C2; long ldc2; int col_split;      // EPI_SPLIT2: columns >= col_split are written to C2[m][n - col_split]
+    const float* bias;                        // [N] or NULL (any mode)
+    float* Cact; long ldact;                  // EPI_ACT: C = acc + bias (pre-activation), Cact = gelu(C)
+    const float* residual; long ldres;        // EPI_RES: C = residual + row_scale * (acc + bias)
+    const float* row_scale; int rows_per_sample;   // any mode: per-row multiplier (NULL = 1)
+    const float* gelu_pre; long ldpre;        // EPI_GELUBWD: C = row_scale * acc * gelu'(gelu_pre[m][n])
     long split_stride;                        // C += split * split_stride (split-R partial slabs)
     float* colsum; int colsum_stride;         // TN only: partial column sums of A (dbias), [split][M]
-
-    __device__ __forceinline__ void store(int m, int n, float v) const {
-        if (bias) v += bias[n];
-        if (gelu_pre) v *= gelu_grad_f(gelu_pre[(long)m * ldpre + n]);
-        if (row_scale) v *= row_scale[m / rows_per_sample];
-        if (residual) v += residual[(long)m * ldres + n];
-        if (C2 && n >= col_split) C2[(long)m * ldc2 + (n - col_split)] = v;
-        else C[(long)m * ldc + n] = v;
-        if (Cact) Cact[(long)m * ldact + n] = gelu_f(v);
-    }
+    int vec_store;                            // 1: every output / auxiliary row is 16-B aligned and N % 4 == 0
+    long long* stamps;                        // debug: per-workgroup s_memtime stamps [nblk][4] (NULL in production)
 };
 
-template <int VEC>
-__device__ __forceinline__ f32x4 load_chunk(const float* p) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (p) {
-        if (VEC == 4) v = *reinterpret_cast<const f32x4*>(p);
+// C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), i.e. a lane owns one
+// COLUMN of the fragment.  Storing from that layout is 16 dword stores per fragment (store-issue bound, measured 20-26 %
+// of a workgroup's life).  Each wave therefore transposes its fragment through a private [32][36] LDS patch so that a
+// lane owns 4 consecutive columns of one row: bias / residual / gelu' operands are read and the result is written
+// with 16-B accesses, 8 full 128-B lines per wave instruction.
+constexpr int EP_LD = 36;
+constexpr int EP_WAVE_FLOATS = 32 * EP_LD;
+
+template <int EPI, int FM, int FN>
+__device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[FM][FN], int M, int N, int mb, int nb,
+                                             int lane, float* wbuf, bool vec) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int rrow = lane >> 3, rcol = (lane & 7) * 4;
+    const bool has_rs = e.row_scale != nullptr;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) wbuf[((g & 3) + 8 * (g >> 2) + 4 * lh) * EP_LD + li] = acc[i][j][g];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int n = nb + j * 32 + rcol;
+            if (vec) {
+                f32x4 bias_v = {0.f, 0.f, 0.f, 0.f};
+                if (e.bias && n < N) bias_v = *reinterpret_cast<const f32x4*>(e.bias + n);
+                f32x4 v[4], aux[4];
+                float rs[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int m = mb + i * 32 + rrow + 8 * p;
+                    const bool ok = m < M && n < N;
+                    v[p] = *reinterpret_cast<const f32x4*>(&wbuf[(rrow + 8 * p) * EP_LD + rcol]);
+                    rs[p] = (has_rs && ok) ? e.row_scale[m / e.rows_per_sample] : 1.0f;
+                    if (EPI == EPI_RES || EPI == EPI_GELUBWD) {
+                        const float* ap = EPI == EPI_RES ? e.residual : e.gelu_pre;
+                        const long ld = EPI == EPI_RES ? e.ldres : e.ldpre;
+                        aux[p] = ok ? *reinterpret_cast<const f32x4*>(ap + (long)m * ld + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int m = mb + i * 32 + rrow + 8 * p;
+                    if (m >= M || n >= N) continue;
+                    f32x4 o = v[p] + bias_v;
+                    if (EPI == EPI_GELUBWD) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] *= gelu_grad_f(aux[p][c]);
+                    }
+                    if (has_rs) o *= rs[p];
+                    if (EPI == EPI_RES) o += aux[p];
+                    if (EPI == EPI_SPLIT2 && n >= e.col_split)
+                        *reinterpret_cast<f32x4*>(e.C2 + (long)m * e.ldc2 + (n - e.col_split)) = o;
+                    else
+                        *reinterpret_cast<f32x4*>(e.C + (long)m * e.ldc + n) = o;
+                    if (EPI == EPI_ACT) {
+                        f32x4 a;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) a[c] = gelu_f(o[c]);
+                        *reinterpret_cast<f32x4*>(e.Cact + (long)m * e.ldact + n) = a;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int m = mb + i * 32 + rrow + 8 * p;
+                    if (m >= M) continue;
+                    const float rsv = has_rs ? e.row_scale[m / e.rows_per_sample] : 1.0f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int nn = n + c;
+                        if (nn >= N) continue;
+                        float o = wbuf[(rrow + 8 * p) * EP_LD + rcol + c] + (e.bias ? e.bias[nn] : 0.f);
+                        if (EPI == EPI_GELUBWD) o *= gelu_grad_f(e.gelu_pre[(long)m * e.ldpre + nn]);
+                        o *= rsv;
+                        if (EPI == EPI_RES) o += e.residual[(long)m * e.ldres + nn];
+                        if (EPI == EPI_SPLIT2 && nn >= e.col_split) e.C2[(long)m * e.ldc2 + (nn - e.col_split)] = o;
+                        else e.C[(long)m * e.ldc + nn] = o;
+                        if (EPI == EPI_ACT) e.Cact[(long)m * e.ldact + nn] = gelu_f(o);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
-    return v;
 }
 
 // ------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------
-template <int BM, int BN, bool A_RC, bool B_RC, int VEC, class ASrc, class BSrc>
+// SCALE_A: multiply the A operand rows by their Row::s (DropPath factor) when staging (weight gradients only)
+template <int BM, int BN, int BK, bool A_RC, bool B_RC, int VEC, int EPI, bool SCALE_A, class ASrc, class BSrc>
 __global__ __launch_bounds__(256) void gemm_kernel(ASrc A, BSrc B, Epilogue epi, int M, int N, int R,
-                                                    int r_per_split, int tiles_m) {
+                                                    int r_per_split, int tiles_m, int tiles_n) {
     constexpr int WM = BM / 2, WN = BN / 2;          // 4 waves as 2 x 2
     constexpr int FM = WM / 32, FN = WN / 32;        // 32x32 fragments per wave
+    constexpr int LDR = BK + 4;                      // [row][r] image: 16-B padded rows -> conflict-free b128 reads
     constexpr int LDA = A_RC ? LDR : BM + 4;
     constexpr int LDB = B_RC ? LDR : BN + 4;
     constexpr int A_ELEMS = A_RC ? BM * LDR : BK * (BM + 4);
     constexpr int B_ELEMS = B_RC ? BN * LDR : BK * (BN + 4);
-    __shared__ __attribute__((aligned(16))) float lds[A_ELEMS + B_ELEMS];
+    constexpr int LDS_FLOATS = (A_ELEMS + B_ELEMS) > 4 * EP_WAVE_FLOATS ? (A_ELEMS + B_ELEMS) : 4 * EP_WAVE_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     float* As = lds;
     float* Bs = lds + A_ELEMS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int tile = blockIdx.x;
-    const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
-    const int split = blockIdx.y;
+    // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so give every XCD a
+    // CONTIGUOUS range of logical blocks, ordered [split][m-tile][n-tile]: the blocks that re-read one A row panel
+    // (all n-tiles of an m-tile; all tiles of a split) then share one L2 instead of fetching it eight times.
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
+    const int lb = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int tiles = tiles_m * tiles_n;
+    const int split = lb / tiles;
+    const int tile = lb - split * tiles;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const int r_begin = split * r_per_split;
     const int r_end = min(R, r_begin + r_per_split);
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
 
     // loader geometry
-    constexpr int QA = BM / 32, QB = BN / 32;               // chunks (16 B) per thread per tile
-    constexpr int A_CPR = A_RC ? 8 : BM / 4;                // chunks per LDS row
-    constexpr int B_CPR = B_RC ? 8 : BN / 4;
+    constexpr int QA = BM * BK / 1024, QB = BN * BK / 1024; // chunks (16 B) per thread per tile
+    constexpr int A_CPR = A_RC ? BK / 4 : BM / 4;           // chunks per LDS row
+    constexpr int B_CPR = B_RC ? BK / 4 : BN / 4;
     constexpr int A_RPP = 256 / A_CPR, B_RPP = 256 / B_CPR; // rows per pass
     const int a_c = tid % A_CPR, a_r = tid / A_CPR;
     const int b_c = tid % B_CPR, b_r = tid / B_CPR;
@@ -189,69 +274,68 @@ __global__ __launch_bounds__(256) void gemm_kernel(ASrc A, BSrc B, Epilogue epi,
         for (int q = 0; q < QB; ++q) brow[q] = B.row(n0 + b_r + q * B_RPP);
     }
 
+    // register prefetch of the next tile: raw loads only -- nothing may consume pa/pb before stash(), or the
+    // compiler waits for the loads in front of the MFMA section
     f32x4 pa[QA], pb[QB];
+    float pas[QA];
     auto fetch = [&](int r0) {
 #pragma unroll
         for (int q = 0; q < QA; ++q) {
+            typename ASrc::Row rr;
+            int j;
             if (A_RC) {
-                int j = r0 + 4 * a_c;
-                if (VEC == 4) {
-                    pa[q] = load_chunk<4>(j < r_end ? A.ptr(arow[q], j) : nullptr) * arow[q].s;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float* p = (j + e < r_end) ? A.ptr(arow[q], j + e) : nullptr;
-                        pa[q][e] = p ? *p * arow[q].s : 0.f;
-                    }
-                }
+                rr = arow[q];
+                j = r0 + 4 * a_c;
             } else {
-                int r = r0 + a_r + q * A_RPP;
-                typename ASrc::Row rr = A.row(r < r_end ? r : 0x7fffffff);
-                int j = m0 + 4 * a_c;
-                if (VEC == 4) {
-                    pa[q] = load_chunk<4>(A.ptr(rr, j)) * rr.s;
-                } else {
+                const int r = r0 + a_r + q * A_RPP;
+                rr = A.row(r < r_end ? r : 0x7fffffff);
+                j = m0 + 4 * a_c;
+            }
+            if (SCALE_A) pas[q] = rr.s;
+            if (VEC == 4) {
+                const float* p = (!A_RC || j < r_end) ? A.ptr(rr, j) : nullptr;
+                pa[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p) pa[q] = *reinterpret_cast<const f32x4*>(p);
+            } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float* p = A.ptr(rr, j + e);
-                        pa[q][e] = p ? *p * rr.s : 0.f;
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    const float* p = (!A_RC || j + e < r_end) ? A.ptr(rr, j + e) : nullptr;
+                    pa[q][e] = p ? *p : 0.f;
                 }
             }
         }
 #pragma unroll
         for (int q = 0; q < QB; ++q) {
+            typename BSrc::Row rr;
+            int j;
             if (B_RC) {
-                int j = r0 + 4 * b_c;
-                if (VEC == 4) {
-                    pb[q] = load_chunk<4>(j < r_end ? B.ptr(brow[q], j) : nullptr) * brow[q].s;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float* p = (j + e < r_end) ? B.ptr(brow[q], j + e) : nullptr;
-                        pb[q][e] = p ? *p * brow[q].s : 0.f;
-                    }
-                }
+                rr = brow[q];
+                j = r0 + 4 * b_c;
             } else {
-                int r = r0 + b_r + q * B_RPP;
-                typename BSrc::Row rr = B.row(r < r_end ? r : 0x7fffffff);
-                int j = n0 + 4 * b_c;
-                if (VEC == 4) {
-                    pb[q] = load_chunk<4>(B.ptr(rr, j)) * rr.s;
-                } else {
+                const int r = r0 + b_r + q * B_RPP;
+                rr = B.row(r < r_end ? r : 0x7fffffff);
+                j = n0 + 4 * b_c;
+            }
+            if (VEC == 4) {
+                const float* p = (!B_RC || j < r_end) ? B.ptr(rr, j) : nullptr;
+                pb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p) pb[q] = *reinterpret_cast<const f32x4*>(p);
+            } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float* p = B.ptr(rr, j + e);
-                        pb[q][e] = p ? *p * rr.s : 0.f;
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    const float* p = (!B_RC || j + e < r_end) ? B.ptr(rr, j + e) : nullptr;
+                    pb[q][e] = p ? *p : 0.f;
                 }
             }
         }
     };
     auto stash = [&]() {
 #pragma unroll
-        for (int q = 0; q < QA; ++q)
-            *reinterpret_cast<f32x4*>(&As[(a_r + q * A_RPP) * LDA + 4 * a_c]) = pa[q];
+        for (int q = 0; q < QA; ++q) {
+            f32x4 v = pa[q];
+            if (SCALE_A) v *= pas[q];
+            *reinterpret_cast<f32x4*>(&As[(a_r + q * A_RPP) * LDA + 4 * a_c]) = v;
+        }
 #pragma unroll
         for (int q = 0; q < QB; ++q)
             *reinterpret_cast<f32x4*>(&Bs[(b_r + q * B_RPP) * LDB + 4 * b_c]) = pb[q];
@@ -266,15 +350,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(ASrc A, BSrc B, Epilogue epi,
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     float csum = 0.f;   // dbias partial (TN, A row-contiguous image: column tid of the A tile)
+    const bool do_colsum = !A_RC && epi.colsum && n0 == 0 && tid < BM;
 
+    if (epi.stamps && tid == 0) epi.stamps[4L * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
     if (r_begin < r_end) {
         fetch(r_begin);
         stash();
         __syncthreads();
+        if (epi.stamps && tid == 0) epi.stamps[4L * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
         for (int r0 = r_begin; r0 < r_end; r0 += BK) {
             const bool more = r0 + BK < r_end;
             if (more) fetch(r0 + BK);
-            if (!A_RC && epi.colsum && n0 == 0 && tid < BM) {
+            if (do_colsum) {
 #pragma unroll 8
                 for (int r = 0; r < BK; ++r) csum += As[r * LDA + tid];
             }
@@ -315,64 +402,58 @@ __global__ __launch_bounds__(256) void gemm_kernel(ASrc A, BSrc B, Epilogue epi,
         }
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    if (epi.stamps && tid == 0) epi.stamps[4L * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
     Epilogue e = epi;
     e.C += (long)split * e.split_stride;
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn0 + j * 32 + li;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int m = m0 + wm0 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
-                if (m < M && n < N) e.store(m, n, acc[i][j][g]);
-            }
-        }
-    if (!A_RC && epi.colsum && n0 == 0 && tid < BM && m0 + tid < M)
-        epi.colsum[(long)split * epi.colsum_stride + m0 + tid] = csum;
+    run_epilogue<EPI, FM, FN>(e, acc, M, N, m0 + wm0, n0 + wn0, lane, lds + wave * EP_WAVE_FLOATS, e.vec_store != 0);
+    if (epi.stamps && tid == 0) epi.stamps[4L * blockIdx.x + 3] = __builtin_amdgcn_s_memtime();
+    if (do_colsum && m0 + tid < M) epi.colsum[(long)split * epi.colsum_stride + m0 + tid] = csum;
 }
 
-// out[i] = sum_s part[s][i]     (split-R slab reduction; deterministic order)
-__global__ void reduce_slabs_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int splits,
-                                    long stride) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += part[(long)k * stride + i];
-    out[i] = s;
-}
-
-template <int BM, int BN, bool A_RC, bool B_RC, int VEC, class ASrc, class BSrc>
+template <int BM, int BN, int BK, bool A_RC, bool B_RC, int VEC, int EPI, bool SCALE_A, class ASrc, class BSrc>
 void launch_cfg(const ASrc& A, const BSrc& B, const Epilogue& epi, int M, int N, int R, int splits, int r_per_split,
                 hipStream_t st) {
     int tm = cdiv(M, BM), tn = cdiv(N, BN);
-    dim3 grid(tm * tn, splits);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, A_RC, B_RC, VEC, ASrc, BSrc>), grid, dim3(256), 0, st, A, B, epi, M, N, R,
-                       r_per_split, tm);
+    dim3 grid(tm * tn * splits);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, A_RC, B_RC, VEC, EPI, SCALE_A, ASrc, BSrc>), grid, dim3(256), 0, st, A, B, epi,
+                       M, N, R, r_per_split, tm, tn);
 }
 
-// tile choice: biggest tile that still gives >= ~2 workgroups per CU; prefer BN that divides N
-template <bool A_RC, bool B_RC, int VEC, class ASrc, class BSrc>
-void launch_gemm(const ASrc& A, const BSrc& B, const Epilogue& epi, int M, int N, int R, int splits, int r_per_split,
+// tile choice (measured on MI355X, tools/gemm_bench.py): the largest tile that still yields >= ~1.5 workgroups per CU
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// 16-B epilogue accesses are legal when every row of every output / auxiliary operand starts 16-B aligned
+inline int epilogue_vec_ok(const Epilogue& e, int n_out) {
+    auto ok = [](const void* p, long ld) { return !p || (aligned16(p) && ld % 4 == 0); };
+    return n_out % 4 == 0 && aligned16(e.C) && e.ldc % 4 == 0 && ok(e.C2, e.ldc2) && (!e.C2 || e.col_split % 4 == 0) &&
+           ok(e.bias, 4) && ok(e.Cact, e.ldact) && ok(e.residual, e.ldres) && ok(e.gelu_pre, e.ldpre) &&
+           e.split_stride % 4 == 0;
+}
+
+template <bool A_RC, bool B_RC, int VEC, int EPI, bool SCALE_A, class ASrc, class BSrc>
+void launch_gemm(const ASrc& A, const BSrc& B, const Epilogue& epi_in, int M, int N, int R, int splits, int r_per_split,
                  hipStream_t st) {
+    Epilogue epi = epi_in;
+    epi.vec_store = epilogue_vec_ok(epi, N);
     auto blocks = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(N, bn) * splits; };
     auto waste = [&](int bn) { return (double)cdiv(N, bn) * bn / N; };
-    const long want = 512;
-    if (blocks(128, 128) >= want && waste(128) <= 1.15)
-        launch_cfg<128, 128, A_RC, B_RC, VEC>(A, B, epi, M, N, R, splits, r_per_split, st);
-    else if (blocks(128, 64) >= want)
-        launch_cfg<128, 64, A_RC, B_RC, VEC>(A, B, epi, M, N, R, splits, r_per_split, st);
-    else
-        launch_cfg<64, 64, A_RC, B_RC, VEC>(A, B, epi, M, N, R, splits, r_per_split, st);
+    static const int forced = getenv("CSWIN_GEMM_TILE") ? atoi(getenv("CSWIN_GEMM_TILE")) : 0;   // tuning aid
+    static const long want = getenv("CSWIN_GEMM_WANT") ? atol(getenv("CSWIN_GEMM_WANT")) : 384;
+    (void)blocks; (void)waste; (void)want;
+    int pick = forced ? forced : 3;
+    if (pick == 1) launch_cfg<128, 128, 32, A_RC, B_RC, VEC, EPI, SCALE_A>(A, B, epi, M, N, R, splits, r_per_split, st);
+    else if (pick == 2) launch_cfg<128, 64, 32, A_RC, B_RC, VEC, EPI, SCALE_A>(A, B, epi, M, N, R, splits, r_per_split, st);
+    else if (pick == 3) launch_cfg<64, 64, 32, A_RC, B_RC, VEC, EPI, SCALE_A>(A, B, epi, M, N, R, splits, r_per_split, st);
+    else launch_cfg<64, 64, 64, A_RC, B_RC, VEC, EPI, SCALE_A>(A, B, epi, M, N, R, splits, r_per_split, st);
 }
 
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+long long* g_stamps = nullptr;     // debug only (cswin_debug_set_stamps)
 
 Epilogue plain_epilogue(float* C, long ldc) {
     Epilogue e = {};
     e.C = C;
     e.ldc = ldc;
+    e.stamps = g_stamps;
     return e;
 }
 
@@ -380,10 +461,10 @@ Epilogue plain_epilogue(float* C, long ldc) {
 void choose_split(int M, int out_rows, int out_cols, int* splits, int* r_per_split) {
     long tiles = (long)cdiv(out_rows, 64) * cdiv(out_cols, 64);
     int s = (int)((768 + tiles - 1) / tiles);
-    int max_s = cdiv(M, 4 * BK);
+    int max_s = cdiv(M, 2 * BKMAX);
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
-    int rps = cdiv(cdiv(M, s), BK) * BK;
+    int rps = cdiv(cdiv(M, s), BKMAX) * BKMAX;
     *splits = cdiv(M, rps);
     *r_per_split = rps;
 }
@@ -394,6 +475,9 @@ void choose_split(int M, int out_rows, int out_cols, int* splits, int* r_per_spl
 // C ABI
 // ======================================================================================
 extern "C" {
+
+// debug aid (not part of include/cswin_hip.h): device buffer [nblk][4] of int64 that GEMM workgroups stamp with s_memtime
+void cswin_debug_set_stamps(void* p) { g_stamps = (long long*)p; }
 
 int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* w, const float* bias, float* y,
                      float* y_act, const float* residual, const float* row_scale, int rows_per_sample, int M, int N,
@@ -408,16 +492,32 @@ int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* 
     e.residual = residual; e.ldres = N;
     e.row_scale = row_scale; e.rows_per_sample = rows_per_sample;
     PlainSrc B = {w, K, N, K, nullptr, 1};
+    CSWIN_REQUIRE(!(y_act && residual), CSWIN_ERR_UNSUPPORTED, "linear_fwd: activation and residual epilogues are exclusive");
+    const int rk = cdiv(K, BKMAX) * BKMAX;
     if (x2) {
+        CSWIN_REQUIRE(!y_act, CSWIN_ERR_UNSUPPORTED, "linear_fwd: concat input does not support the activation epilogue");
         ConcatSrc A = {x, x2, k_split, K - k_split, M, K, k_split};
         bool vec = (k_split % 4 == 0) && (K % 4 == 0) && aligned16(x) && aligned16(x2) && aligned16(w);
-        if (vec) launch_gemm<true, true, 4>(A, B, e, M, N, K, 1, cdiv(K, BK) * BK, st);
-        else launch_gemm<true, true, 1>(A, B, e, M, N, K, 1, cdiv(K, BK) * BK, st);
+        if (residual) {
+            if (vec) launch_gemm<true, true, 4, EPI_RES, false>(A, B, e, M, N, K, 1, rk, st);
+            else launch_gemm<true, true, 1, EPI_RES, false>(A, B, e, M, N, K, 1, rk, st);
+        } else {
+            if (vec) launch_gemm<true, true, 4, EPI_PLAIN, false>(A, B, e, M, N, K, 1, rk, st);
+            else launch_gemm<true, true, 1, EPI_PLAIN, false>(A, B, e, M, N, K, 1, rk, st);
+        }
     } else {
         PlainSrc A = {x, K, M, K, nullptr, 1};
         bool vec = (K % 4 == 0) && aligned16(x) && aligned16(w);
-        if (vec) launch_gemm<true, true, 4>(A, B, e, M, N, K, 1, cdiv(K, BK) * BK, st);
-        else launch_gemm<true, true, 1>(A, B, e, M, N, K, 1, cdiv(K, BK) * BK, st);
+        if (y_act) {
+            if (vec) launch_gemm<true, true, 4, EPI_ACT, false>(A, B, e, M, N, K, 1, rk, st);
+            else launch_gemm<true, true, 1, EPI_ACT, false>(A, B, e, M, N, K, 1, rk, st);
+        } else if (residual) {
+            if (vec) launch_gemm<true, true, 4, EPI_RES, false>(A, B, e, M, N, K, 1, rk, st);
+            else launch_gemm<true, true, 1, EPI_RES, false>(A, B, e, M, N, K, 1, rk, st);
+        } else {
+            if (vec) launch_gemm<true, true, 4, EPI_PLAIN, false>(A, B, e, M, N, K, 1, rk, st);
+            else launch_gemm<true, true, 1, EPI_PLAIN, false>(A, B, e, M, N, K, 1, rk, st);
+        }
     }
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
@@ -440,8 +540,22 @@ int cswin_linear_bwd_data(const float* dy, const float* w, float* dx, float* dx2
     PlainSrc B = {w, K, N, K, nullptr, 1};     // S(i = n (reduction), j = k): row-contiguous image
     bool vec = (N % 4 == 0) && (K % 4 == 0) && aligned16(dy) && aligned16(w);
     // output rows = M, output cols = K, reduction = N
-    if (vec) launch_gemm<true, false, 4>(A, B, e, M, K, N, 1, cdiv(N, BK) * BK, st);
-    else launch_gemm<true, false, 1>(A, B, e, M, K, N, 1, cdiv(N, BK) * BK, st);
+    const int rn = cdiv(N, BKMAX) * BKMAX;
+    const int modes = (dx2 != nullptr) + (gelu_pre != nullptr) + (add != nullptr);
+    CSWIN_REQUIRE(modes <= 1, CSWIN_ERR_UNSUPPORTED, "linear_bwd_data: dx2 / gelu_pre / add are mutually exclusive");
+    if (dx2) {
+        if (vec) launch_gemm<true, false, 4, EPI_SPLIT2, false>(A, B, e, M, K, N, 1, rn, st);
+        else launch_gemm<true, false, 1, EPI_SPLIT2, false>(A, B, e, M, K, N, 1, rn, st);
+    } else if (gelu_pre) {
+        if (vec) launch_gemm<true, false, 4, EPI_GELUBWD, false>(A, B, e, M, K, N, 1, rn, st);
+        else launch_gemm<true, false, 1, EPI_GELUBWD, false>(A, B, e, M, K, N, 1, rn, st);
+    } else if (add) {
+        if (vec) launch_gemm<true, false, 4, EPI_RES, false>(A, B, e, M, K, N, 1, rn, st);
+        else launch_gemm<true, false, 1, EPI_RES, false>(A, B, e, M, K, N, 1, rn, st);
+    } else {
+        if (vec) launch_gemm<true, false, 4, EPI_PLAIN, false>(A, B, e, M, K, N, 1, rn, st);
+        else launch_gemm<true, false, 1, EPI_PLAIN, false>(A, B, e, M, K, N, 1, rn, st);
+    }
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }
@@ -464,28 +578,33 @@ int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, in
     hipStream_t st = (hipStream_t)stream;
     int splits, rps;
     choose_split(M, N, K, &splits, &rps);
+    // slab s = [dw partial (N*K) | dbias partial (N)]: one reduction launch serves both
     float* slab = (float*)workspace;
-    float* bslab = slab + (size_t)splits * N * K;
+    const long slab_stride = (long)N * K + N;
     Epilogue e = plain_epilogue(slab, K);
-    e.split_stride = (long)N * K;
-    e.colsum = dbias ? bslab : nullptr;
-    e.colsum_stride = N;
+    e.split_stride = slab_stride;
+    e.colsum = dbias ? slab + (long)N * K : nullptr;
+    e.colsum_stride = (int)slab_stride;
     PlainSrc A = {dy, N, M, N, row_scale, rows_per_sample};      // S(i = m (reduction), j = n)
     if (x2) {
         ConcatSrc B = {x, x2, k_split, K - k_split, M, K, k_split};
         bool vec = (N % 4 == 0) && (K % 4 == 0) && (k_split % 4 == 0) && aligned16(dy) && aligned16(x) && aligned16(x2);
-        if (vec) launch_gemm<false, false, 4>(A, B, e, N, K, M, splits, rps, st);
-        else launch_gemm<false, false, 1>(A, B, e, N, K, M, splits, rps, st);
+        if (vec) launch_gemm<false, false, 4, EPI_PLAIN, true>(A, B, e, N, K, M, splits, rps, st);
+        else launch_gemm<false, false, 1, EPI_PLAIN, true>(A, B, e, N, K, M, splits, rps, st);
     } else {
         PlainSrc B = {x, K, M, K, nullptr, 1};
         bool vec = (N % 4 == 0) && (K % 4 == 0) && aligned16(dy) && aligned16(x);
-        if (vec) launch_gemm<false, false, 4>(A, B, e, N, K, M, splits, rps, st);
-        else launch_gemm<false, false, 1>(A, B, e, N, K, M, splits, rps, st);
+        if (row_scale) {
+            if (vec) launch_gemm<false, false, 4, EPI_PLAIN, true>(A, B, e, N, K, M, splits, rps, st);
+            else launch_gemm<false, false, 1, EPI_PLAIN, true>(A, B, e, N, K, M, splits, rps, st);
+        } else {
+            if (vec) launch_gemm<false, false, 4, EPI_PLAIN, false>(A, B, e, N, K, M, splits, rps, st);
+            else launch_gemm<false, false, 1, EPI_PLAIN, false>(A, B, e, N, K, M, splits, rps, st);
+        }
     }
     CSWIN_LAUNCH_CHECK();
     long n = (long)N * K;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, slab, dw, n, splits, n);
-    if (dbias) hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, bslab, dbias, (long)N, splits, (long)N);
+    launch_rows_sum(slab, dw, dbias, n, n + (dbias ? N : 0), splits, slab_stride, st);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }
@@ -502,7 +621,7 @@ int cswin_conv_tok_fwd(const float* x, const float* w_perm, const float* bias, f
     PlainSrc Bm = {w_perm, R, Cout, R, nullptr, 1};
     Epilogue e = plain_epilogue(y, Cout);
     e.bias = bias;
-    launch_gemm<true, true, 4>(A, Bm, e, M, Cout, R, 1, cdiv(R, BK) * BK, (hipStream_t)stream);
+    launch_gemm<true, true, 4, EPI_PLAIN, false>(A, Bm, e, M, Cout, R, 1, cdiv(R, BKMAX) * BKMAX, (hipStream_t)stream);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }
@@ -517,7 +636,7 @@ int cswin_conv_tok_bwd_data(const float* dy, const float* w_permT, float* dx, in
     ConvTSrc A = {dy, B, H, W, Cout, OH, OW, ks, stride, pad, M, R};
     PlainSrc Bm = {w_permT, Cin, R, Cin, nullptr, 1};          // S(i = (tap, co), j = ci)
     Epilogue e = plain_epilogue(dx, Cin);
-    launch_gemm<true, false, 4>(A, Bm, e, M, Cin, R, 1, cdiv(R, BK) * BK, (hipStream_t)stream);
+    launch_gemm<true, false, 4, EPI_PLAIN, false>(A, Bm, e, M, Cin, R, 1, cdiv(R, BKMAX) * BKMAX, (hipStream_t)stream);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }
@@ -541,18 +660,17 @@ int cswin_conv_tok_bwd_weight(const float* dy, const float* x, float* dw_perm, f
     int splits, rps;
     choose_split(M, Cout, K, &splits, &rps);
     float* slab = (float*)workspace;
-    float* bslab = slab + (size_t)splits * Cout * K;
+    const long slab_stride = (long)Cout * K + Cout;
     Epilogue e = plain_epilogue(slab, K);
-    e.split_stride = (long)Cout * K;
-    e.colsum = dbias ? bslab : nullptr;
-    e.colsum_stride = Cout;
+    e.split_stride = slab_stride;
+    e.colsum = dbias ? slab + (long)Cout * K : nullptr;
+    e.colsum_stride = (int)slab_stride;
     PlainSrc A = {dy, Cout, M, Cout, nullptr, 1};
     ConvSrc Bm = {x, B, H, W, Cin, OH, OW, ks, stride, pad, M, K};   // S(i = pixel m (reduction), j = (tap, ci))
-    launch_gemm<false, false, 4>(A, Bm, e, Cout, K, M, splits, rps, st);
+    launch_gemm<false, false, 4, EPI_PLAIN, false>(A, Bm, e, Cout, K, M, splits, rps, st);
     CSWIN_LAUNCH_CHECK();
     long n = (long)Cout * K;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, slab, dw_perm, n, splits, n);
-    if (dbias) hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(Cout, 256)), dim3(256), 0, st, bslab, dbias, (long)Cout, splits, (long)Cout);
+    launch_rows_sum(slab, dw_perm, dbias, n, n + (dbias ? Cout : 0), splits, slab_stride, st);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }

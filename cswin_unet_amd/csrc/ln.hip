@@ -128,17 +128,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
-__global__ void ln_reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                          float* __restrict__ dbeta, int C, int nblk) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * C) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(long)b * 2 * C + c];
-    if (c < C) dgamma[c] = s;
-    else dbeta[c - C] = s;
-}
-
-int ln_grid(int M, int rpb) { return min(cdiv(M, rpb), 1024); }
+int ln_grid(int M, int rpb) { return min(cdiv(M, rpb), 512); }
 
 template <int LPR, int VPL>
 void launch_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int M, float eps,
@@ -199,7 +189,7 @@ int cswin_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
         case 1024: launch_bwd<64, 4>(dy, x, mean, rstd, gamma, dres, dx, partial, M, st); break;
     }
     CSWIN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_reduce_partials_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, partial, dgamma, dbeta, C, nblk);
+    launch_rows_sum(partial, dgamma, dbeta, C, 2L * C, nblk, 2L * C, st);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }

@@ -57,14 +57,6 @@ __global__ __launch_bounds__(256) void loss_sums_kernel(const float* __restrict_
         partial[(long)blockIdx.x * NV + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ void loss_sums_reduce_kernel(const float* __restrict__ partial, float* __restrict__ sums, int nv, int nblk) {
-    const int i = threadIdx.x;
-    if (i >= nv) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partial[(long)b * nv + i];
-    sums[i] = (float)s;
-}
-
 // out[0..2] = loss, ce, dice;  coef[c] = a_c, coef[ncls + c] = b_c with d dice_c / d p_c(pixel) = a_c * onehot + b_c * p
 __global__ void loss_finalize_kernel(const float* __restrict__ sums, float* __restrict__ out, float* __restrict__ coef,
                                      float n_pixels, int ncls, float w_ce, float w_dice) {
@@ -135,7 +127,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
 
 int loss_blocks(long total) {
     long b = (total + 255) / 256;
-    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
 }
 
 #define NC_SWITCH(NCV, CALL)                                                                     \
@@ -168,7 +160,7 @@ int cswin_loss_sums(const float* logits, const long long* labels, float* sums, v
     const int nblk = loss_blocks((long)B * HW);
     NC_SWITCH(ncls, hipLaunchKernelGGL(loss_sums_kernel<NC>, dim3(nblk), dim3(256), 0, st, logits, labels, (float*)workspace, B, HW));
     CSWIN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(loss_sums_reduce_kernel, dim3(1), dim3(64), 0, st, (const float*)workspace, sums, 1 + 3 * ncls, nblk);
+    launch_rows_sum((const float*)workspace, sums, nullptr, 0, 1 + 3 * ncls, nblk, 1 + 3 * ncls, st);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }

@@ -38,7 +38,12 @@ class FlatSGD:
                 p.data = view                       # parameters now alias the flat buffer
         self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
         self.lr = float(lr)
-        self._table, self._table_key = None, None
+        # gather table: one {src, dst, n} record per <= 16 Ki-float chunk.  dst/n are fixed; src follows p.grad.
+        # Host side is pinned and allocated here, so refreshing it inside a hipGraph capture allocates nothing.
+        nrows = sum((p.numel() + _CHUNK - 1) // _CHUNK for p in self.params)
+        self._table_host = torch.zeros(nrows, 3, dtype=torch.int64).pin_memory()
+        self._table = torch.zeros(nrows, 3, dtype=torch.int64, device=dev)
+        self._table_key = None
         self.param_groups = [{"lr": self.lr, "params": self.params}]   # torch.optim-like view for loops that poke lr
 
     # -- schedule -------------------------------------------------------------------------------------------
@@ -65,7 +70,12 @@ class FlatSGD:
                 n = p.numel()
                 for c in range(0, n, _CHUNK):
                     rows.append((src + 4 * c, base + 4 * (o + c), min(_CHUNK, n - c)))
-            self._table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(self.flat_grad.device)
+            capturing = torch.cuda.is_current_stream_capturing()
+            if not capturing:
+                torch.cuda.current_stream().synchronize()      # a previous async upload may still read the host buffer
+            self._table_host.numpy()[:] = np.asarray(rows, dtype=np.int64)
+            # async upload from pinned memory: a memcpy node when captured (the host buffer lives with the optimiser)
+            self._table.copy_(self._table_host, non_blocking=True)
             self._table_key = key
         return self._table
 

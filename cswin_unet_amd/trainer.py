@@ -1,0 +1,204 @@
+"""Data-parallel training step for CSWin-UNet on MI355X (counterpart of the reference's trainer.py:20-95).
+
+Same objective and schedule as ``trainer_synapse``: loss = 0.4*CE + 0.6*Dice (trainer.py:55-57), SGD momentum 0.9 /
+weight decay 1e-4 (:42), poly learning rate base_lr*(1 - it/max_it)^0.9 applied after the step (:61-63).  What changes is
+the execution model, MI355X-first:
+
+  * one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI) instead of the reference's single-process
+    nn.DataParallel (:37-38): replicas are persistent, only gradients travel.
+  * the reference computes the loss on the gathered GLOBAL batch; CE is linear in the per-rank means but soft Dice is
+    not, so the 1 + 3*ncls partial sums are all-reduced before the Dice ratio is formed (28 floats) -- the objective
+    is the reference's, not a per-rank Dice.
+  * gradients are packed by one multi-tensor launch into a flat buffer which is all-reduced in a few large buckets
+    (sized for 7 point-to-point xGMI links, not for many small NVSwitch messages) and consumed by one fused SGD launch.
+  * the step is captured into two hipGraphs (forward + loss sums | loss backward + model backward + gradient packing)
+    with the two collectives between/after them, so ~1500 kernel launches cost two graph launches on the host.
+
+The protocol (which collectives, which scalings) lives in ``DataParallelTrainer`` and is device agnostic; the device work
+lives in an *engine*.  ``HipEngine`` is the product (C ABI kernels, hipGraphs).  tests/test_dp_gloo.py drives the same
+protocol with a CPU engine over gloo to check 2-rank == 1-rank-global-batch semantics without a GPU.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from ._lib import call, lib, ptr, stream
+from .optim import FlatSGD
+
+
+def init_distributed():
+    """(rank, local_rank, world, group).  torchrun / torch.distributed.run environment; world 1 needs nothing."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world, (dist.group.WORLD if world > 1 else None)
+
+
+def synthetic_batch(batch, img_size, num_classes, seed, device):
+    """Synthetic stand-in for a Synapse minibatch (datasets/dataset_synapse.py:62-69 after RandomGenerator):
+    image (B, 1, H, W) fp32 ~ N(0,1), label (B, H, W) int64 uniform in [0, num_classes)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    img = torch.randn(batch, 1, img_size, img_size, generator=g)
+    lab = torch.randint(0, num_classes, (batch, img_size, img_size), generator=g)
+    return img.to(device), lab.to(device)
+
+
+def poly_lr(base_lr, iter_num, max_iterations):
+    return base_lr * (1.0 - iter_num / max_iterations) ** 0.9
+
+
+def scale_lr_for_batch(base_lr, batch_size):
+    """train.py:104-105: base_lr *= batch_size / 24 only when batch_size != 24 and batch_size % 6 == 0 (per-GPU batch)."""
+    return base_lr * batch_size / 24 if (batch_size != 24 and batch_size % 6 == 0) else base_lr
+
+
+class HipEngine:
+    """Device side of one training step on this rank's MI355X: C-ABI kernels, optionally replayed from two hipGraphs."""
+
+    def __init__(self, model, num_classes, lr, momentum, weight_decay, w_ce, w_dice, use_graph=True):
+        self.model, self.ncls, self.w_ce, self.w_dice = model, num_classes, w_ce, w_dice
+        self.opt = FlatSGD(model.parameters(), lr=lr, momentum=momentum, weight_decay=weight_decay)
+        dev = self.opt.flat_param.device
+        self.sums = torch.zeros(1 + 3 * num_classes, dtype=torch.float32, device=dev)
+        self.stats = torch.zeros(3, dtype=torch.float32, device=dev)          # [loss, ce, dice] of the last step
+        self._coef = torch.zeros(2 * num_classes, dtype=torch.float32, device=dev)
+        self.use_graph, self._graphs, self._logits = use_graph, None, None
+
+    # flat views the protocol all-reduces / broadcasts
+    @property
+    def flat_param(self):
+        return self.opt.flat_param
+
+    @property
+    def flat_grad(self):
+        return self.opt.flat_grad
+
+    def set_lr(self, lr):
+        self.opt.set_lr(lr)
+
+    # ---- eager pieces -------------------------------------------------------------------------------------------
+    def _forward_sums(self, img, lab):
+        logits = self.model(img)
+        B, ncls = logits.shape[:2]
+        hw = logits.numel() // (B * ncls)
+        nbytes = lib().cswin_loss_workspace(B, ncls, hw)
+        ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=logits.device)
+        call("cswin_loss_sums", ptr(logits.detach()), ptr(lab), ptr(self.sums), ptr(ws), nbytes, B, ncls, hw, stream())
+        return logits
+
+    def _backward_pack(self, logits, lab, dice_grad_scale):
+        B, ncls = logits.shape[:2]
+        hw = logits.numel() // (B * ncls)
+        dlogits = torch.empty_like(logits)
+        call("cswin_loss_bwd", ptr(logits.detach()), ptr(lab), ptr(self._coef), None, ptr(dlogits),
+             self.w_ce / float(B * hw), self.w_dice / ncls * dice_grad_scale, B, ncls, hw, stream())
+        self.opt.zero_grad()
+        logits.backward(dlogits)
+        self.opt.gather_grads()
+
+    def _capture(self, img, lab, dice_grad_scale):
+        # PyTorch's capture recipe: a few eager iterations on a side stream (allocator state and autograd's
+        # AccumulateGrad nodes then belong to a non-default stream), then capture both halves into one memory pool
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                logits = self._forward_sums(img, lab)
+                self.finalize(lab.numel())
+                self._backward_pack(logits, lab, dice_grad_scale)
+        torch.cuda.current_stream().wait_stream(side)
+        self._img, self._lab = img.clone(), lab.clone()
+        self.opt.zero_grad()
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            logits = self._forward_sums(self._img, self._lab)
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            self._backward_pack(logits, self._lab, dice_grad_scale)
+        self._graphs = (ga, gb)
+
+    # ---- protocol hooks -----------------------------------------------------------------------------------------
+    def forward_sums(self, img, lab, dice_grad_scale):
+        """Forward + local loss partial sums -> self.sums (device)."""
+        if self.use_graph and self._graphs is None:
+            self._capture(img, lab, dice_grad_scale)
+        if self._graphs is not None:
+            if img.data_ptr() != self._img.data_ptr():
+                self._img.copy_(img)
+                self._lab.copy_(lab)
+            self._graphs[0].replay()
+        else:
+            self._logits = self._forward_sums(img, lab)
+            self._lab_eager = lab
+
+    def finalize(self, n_pixels_global):
+        """sums (already all-reduced) -> stats [loss, ce, dice] and the Dice gradient coefficients."""
+        call("cswin_loss_finalize", ptr(self.sums), ptr(self.stats), ptr(self._coef), float(n_pixels_global), self.ncls,
+             self.w_ce, self.w_dice, stream())
+
+    def backward_pack(self, dice_grad_scale):
+        """Loss backward + model backward + gradient packing -> self.flat_grad."""
+        if self._graphs is not None:
+            self._graphs[1].replay()
+        else:
+            self._backward_pack(self._logits, self._lab_eager, dice_grad_scale)
+            self._logits = None
+
+    def apply(self, grad_scale):
+        self.opt.apply(grad_scale)
+
+
+class DataParallelTrainer:
+    """The data-parallel protocol of one step (device agnostic; see module docstring)."""
+
+    def __init__(self, model=None, num_classes=9, base_lr=0.05, max_iterations=1000, momentum=0.9, weight_decay=1e-4,
+                 group=None, use_graph=True, buckets=4, w_ce=0.4, w_dice=0.6, engine=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if group is not None else 1
+        self.base_lr, self.max_iterations, self.iter_num = base_lr, max_iterations, 0
+        self.engine = engine if engine is not None else HipEngine(model, num_classes, base_lr, momentum, weight_decay,
+                                                                 w_ce, w_dice, use_graph)
+        self.model = model
+        self.nbuckets = max(1, buckets)
+        if self.world > 1:                      # identical replicas: rank 0's initial weights everywhere
+            dist.broadcast(self.engine.flat_param, src=0, group=group)
+
+    @property
+    def stats(self):
+        return self.engine.stats
+
+    def train_step(self, img, lab):
+        """One optimisation step on this rank's shard.  Returns the device tensor [loss, ce, dice] (no host sync)."""
+        if lab.dtype != torch.int64:
+            lab = lab.long()
+        lab = lab.contiguous()
+        eng, world = self.engine, self.world
+        # Dice is a function of GLOBAL sums; gradients are averaged over ranks afterwards, so the local Dice gradient
+        # (already built from global coefficients) is pre-multiplied by world to survive the 1/world averaging.
+        eng.forward_sums(img, lab, dice_grad_scale=float(world))
+        if world > 1:
+            dist.all_reduce(eng.sums, group=self.group)                 # 1 + 3*ncls floats
+        eng.finalize(lab.numel() * world)
+        eng.backward_pack(dice_grad_scale=float(world))
+        if world > 1:
+            g = eng.flat_grad
+            n = g.numel()
+            step = (n + self.nbuckets - 1) // self.nbuckets
+            works = [dist.all_reduce(g[o:min(o + step, n)], group=self.group, async_op=True) for o in range(0, n, step)]
+            for w in works:
+                w.wait()
+        eng.apply(grad_scale=1.0 / world)
+        self.iter_num += 1
+        eng.set_lr(poly_lr(self.base_lr, self.iter_num - 1, self.max_iterations))   # trainer.py:61-63
+        return eng.stats
+
+    def state_dict(self):
+        """Reference checkpoint format: the model's state_dict (trainer.py:84)."""
+        return self.model.state_dict()

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""In-kernel timeline of one GEMM launch: gemm_stamps.py M N K mode(fwd|dx)"""
+import os, sys, ctypes
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cswin_unet_amd._lib import call, lib, ptr, stream
+M, N, K = (int(a) for a in sys.argv[1:4]); mode = sys.argv[4]
+x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda"); b = torch.randn(N, device="cuda")
+dy = torch.randn(M, N, device="cuda"); y = torch.empty(M, N, device="cuda"); dx = torch.empty(M, K, device="cuda")
+st = torch.zeros(65536, 4, dtype=torch.int64, device="cuda")
+h = lib(); h.cswin_debug_set_stamps.argtypes = [ctypes.c_void_p]
+def run():
+    if mode == "fwd": call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, stream())
+    else: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, stream())
+for _ in range(3): run()
+torch.cuda.synchronize()
+h.cswin_debug_set_stamps(ctypes.c_void_p(st.data_ptr()))
+run(); torch.cuda.synchronize()
+h.cswin_debug_set_stamps(None)
+s = st.cpu().numpy(); s = s[s[:, 0] != 0]
+t0 = s[:, 0].min()
+print(f"{mode} M={M} N={N} K={K} blocks={len(s)}")
+print("kernel span (cycles):", s[:, 3].max() - t0)
+for name, a, b_ in (("prologue", 0, 1), ("mainloop", 1, 2), ("epilogue", 2, 3), ("total", 0, 3)):
+    d = s[:, b_] - s[:, a]
+    print(f"  {name:9s} mean {d.mean():9.0f}  p10 {np.percentile(d,10):9.0f}  p90 {np.percentile(d,90):9.0f} cycles")
+st_rel = s[:, 0] - t0
+print("  start offsets: p50 %d p90 %d max %d ; end offsets: p10 %d p50 %d max %d" % (np.percentile(st_rel,50), np.percentile(st_rel,90), st_rel.max(), np.percentile(s[:,3]-t0,10), np.percentile(s[:,3]-t0,50), (s[:,3]-t0).max()))
