@@ -31,12 +31,37 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def attention_roofline(batch, cfg, reps=20):
-    """Times attn fwd / bwd for the four stage shapes of the model at this batch.  Returns the roofline object."""
-    from cswin_unet_amd import ops
+def _graph_time(fn, reps=20, rounds=5):
+    """Average device time of one call: `reps` launches captured in a hipGraph on the current stream, replayed between
+    two HIP events on that same stream (host launch overhead excluded; best of `rounds`)."""
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e-3 / reps)
+    return best
+
+
+def attention_roofline(batch, cfg, img_size=224):
+    """Times the fused stripe-attention kernels for the four stage shapes of the model at this batch through the C ABI.
+    Algorithmic FLOPs: QK^T + PV = 4*L*N*C per block per image forward; backward = 2x that (dQ, dK, dV, dP).
+    Algorithmic bytes: q,k,v in + y out = 16*L*C per block per image forward; backward q,k,v,dy in + dqkv out = 28*L*C."""
+    import ctypes
+    from cswin_unet_amd._lib import call, lib, ptr, stream
     dev = "cuda"
     E, depth, heads, split = cfg.EMBED_DIM, cfg.DEPTH, cfg.NUM_HEADS, cfg.SPLIT_SIZE
-    reso0 = 224 // 4
+    reso0 = img_size // 4
     rows, tot_flops, tot_time, tot_bytes = [], 0.0, 0.0, 0.0
     g = torch.Generator(device="cpu").manual_seed(7)
     for si in range(4):
@@ -45,45 +70,36 @@ def attention_roofline(batch, cfg, reps=20):
         single = si == 3 or reso == split[si]
         idx = [-1] if single else [0, 1]
         hb = [heads[si]] if single else [heads[si] // 2] * 2
-        cb = C // len(idx)
-        n_win = reso * reso if single else reso * split[si]
-        qkv = torch.randn(batch, L, 3 * C, generator=g).to(dev).requires_grad_()
-        w = [(torch.randn(cb, 1, 3, 3, generator=g) / 3).to(dev).requires_grad_() for _ in idx]
-        b = [(torch.randn(cb, generator=g) * 0.02).to(dev).requires_grad_() for _ in idx]
+        nb, cb = len(idx), C // len(idx)
+        n_tok = reso * reso if single else reso * split[si]
+        qkv = torch.randn(batch, L, 3 * C, generator=g).to(dev)
+        w = [(torch.randn(cb, 9, generator=g) / 3).to(dev) for _ in idx]
+        b = [(torch.randn(cb, generator=g) * 0.02).to(dev) for _ in idx]
         dy = torch.randn(batch, L, C, generator=g).to(dev)
-        fwd = lambda: ops.stripe_attention(qkv, reso, split[si], idx, hb, w, b)
-
-        def timed(fn):
-            fn()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) * 1e-3 / reps
-
-        with torch.no_grad():
-            t_f = timed(fwd)
-        y = fwd()
-
-        def bwd():
-            qkv.grad = None
-            y.backward(dy, retain_graph=True)
-        t_fb = timed(bwd)                       # backward only (forward output retained): attn_bwd + lepe reduce
-        flops_f = 4.0 * L * n_win * C * batch    # QK^T + PV, 2*MAC
+        y = torch.empty(batch, L, C, device=dev)
+        lse = torch.empty(batch, sum(hb), L, device=dev)
+        dqkv = torch.empty_like(qkv)
+        dw, db = [torch.empty_like(t) for t in w], [torch.empty_like(t) for t in b]
+        ia, ha = (ctypes.c_int * nb)(*idx), (ctypes.c_int * nb)(*hb)
+        pa = lambda ts: (ctypes.c_void_p * nb)(*[t.data_ptr() for t in ts])
+        nbytes = lib().cswin_attn_bwd_workspace(batch, reso, C, nb, ha, ia, split[si])
+        ws = torch.empty(nbytes // 4 + 4, device=dev)
+        t_f = _graph_time(lambda: call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(lse), batch, reso, C, nb, ha, ia,
+                                       split[si], 0.0, stream()))
+        t_b = _graph_time(lambda: call("cswin_attn_bwd", ptr(qkv), pa(w), ptr(lse), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws),
+                                       nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, stream()))
+        flops_f = 4.0 * L * n_tok * C * batch
         n_blocks = 2 * depth[si]
-        bytes_f = 16.0 * L * C * batch           # read q,k,v + write y (fp32)
-        rows.append({"stage": si + 1, "window_tokens": n_win, "launches_per_step": n_blocks,
-                     "fwd_us": round(t_f * 1e6, 2), "bwd_us": round(t_fb * 1e6, 2),
-                     "fwd_tflops": round(flops_f / t_f / 1e12, 2), "bwd_tflops": round(2 * flops_f / t_fb / 1e12, 2),
-                     "fwd_hbm_gbps": round(bytes_f / t_f / 1e9, 1)})
+        bytes_f, bytes_b = 16.0 * L * C * batch, 28.0 * L * C * batch
+        rows.append({"stage": si + 1, "window_tokens": n_tok, "launches_per_step": n_blocks,
+                     "fwd_us": round(t_f * 1e6, 2), "bwd_us": round(t_b * 1e6, 2),
+                     "fwd_tflops": round(flops_f / t_f / 1e12, 2), "bwd_tflops": round(2 * flops_f / t_b / 1e12, 2),
+                     "fwd_hbm_gbps": round(bytes_f / t_f / 1e9, 1), "bwd_hbm_gbps": round(bytes_b / t_b / 1e9, 1)})
         tot_flops += n_blocks * 3.0 * flops_f
-        tot_time += n_blocks * (t_f + t_fb)
-        tot_bytes += n_blocks * 3.0 * bytes_f
+        tot_time += n_blocks * (t_f + t_b)
+        tot_bytes += n_blocks * (bytes_f + bytes_b)
     achieved = tot_flops / tot_time / 1e12
-    return {"kernel": "attn_fwd_kernel + attn_bwd_kernel (all 26 blocks, fwd+bwd)", "bound": "mfma",
+    return {"kernel": "attn_fwd_kernel + attn_bwd_kernel (+ lepe_grad_reduce), all 26 blocks of one step", "bound": "mfma",
             "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
             "algorithmic_gflop_per_step": round(tot_flops / 1e9, 2), "time_per_step_ms": round(tot_time * 1e3, 3),
@@ -94,16 +110,20 @@ def cpu_baseline(batch, steps=2):
     """The CPU oracle's training step (same model, loss, optimiser, synthetic batch) on the host cores."""
     from oracle import cswin_oracle as O
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, int(os.environ.get("CSWIN_CPU_THREADS", "16"))))   # a 1-GPU box's CPU share is 16 cores
     torch.set_num_threads(cores)
+    log(f"[bench] cpu baseline: oracle training step, batch {batch}, {cores} threads ...")
     g = torch.Generator().manual_seed(1234)
     P = O.golden_params()
     img = torch.randn(batch, 1, 224, 224, generator=g)
     lab = torch.randint(0, 9, (batch, 224, 224), generator=g)
     M = {}
     O.train_step(P, M, img, lab, 0.05)          # warm-up
+    log(f"[bench] cpu baseline: warm-up step done")
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
         O.train_step(P, M, img, lab, 0.05)
+        log(f"[bench] cpu baseline: step {i + 1}/{steps} at {time.perf_counter() - t0:.1f}s")
     dt = (time.perf_counter() - t0) / steps
     return {"value": round(batch / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"{steps} timed training steps (+1 warm-up) of batch {batch}, cswin_tiny_224_lite fp32, "
@@ -141,6 +161,7 @@ def main():
                                   use_graph=not args.no_graph)
     img, lab = synthetic_batch(args.batch, config.DATA.IMG_SIZE, num_classes, 1234 + rank, dev)
 
+    log(f"[bench] rank {rank}/{world}: model built, capturing ...")
     for _ in range(2):                      # set-up steps (eager warm-up + hipGraph capture happen in the first), not part of W
         trainer.train_step(img, lab)
     for _ in range(args.warmup):
@@ -162,6 +183,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = [float(v) for v in stats.tolist()]
+    log(f"[bench] timed region done: {elapsed / args.steps * 1e3:.3f} ms/step")
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -176,7 +198,8 @@ def main():
                "final_loss": {"loss": round(loss[0], 5), "ce": round(loss[1], 5), "dice": round(loss[2], 5)},
                "model_tflops": round(33.2e9 * world * args.batch * args.steps / elapsed / 1e12, 2)}
         if world == 1 and not args.skip_roofline:
-            out["roofline"] = attention_roofline(args.batch, config.MODEL.CSWIN)
+            log("[bench] attention roofline sub-benchmark ...")
+            out["roofline"] = attention_roofline(args.batch, config.MODEL.CSWIN, config.DATA.IMG_SIZE)
         if world == 1 and not args.skip_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
         print(json.dumps(out), flush=True)
