@@ -97,6 +97,19 @@ __global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnPa
     const int N = w.N;
     const float* qkv_b = p.qkv + (long)w.b * L * C3;
 
+    // this wave's first query tile: issue its Q loads first so their latency overlaps the K/V staging below
+    f32x4 q0_pre = {0.f, 0.f, 0.f, 0.f}, q1_pre = q0_pre;
+    int lq_pre = 0;
+    {
+        const int tq = 16 * wave + li;
+        if (wave < NT && tq < N) {
+            lq_pre = token_of(br, w, p.reso, tq);
+            const float* src = qkv_b + (long)lq_pre * C3 + ch0 + 8 * kq;
+            q0_pre = *reinterpret_cast<const f32x4*>(src);
+            q1_pre = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+    }
+
     for (int idx = tid; idx < NP * 8; idx += 64 * NW) {
         const int row = idx >> 3, c4 = idx & 7;
         f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
@@ -118,14 +131,19 @@ __global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnPa
     for (int qt = wave; qt < NT; qt += NW) {
         const int tq = 16 * qt + li;
         const bool qvalid = tq < N;
-        const int lq = qvalid ? token_of(br, w, p.reso, tq) : 0;
+        int lq = lq_pre;
         float qr[8];
         {
-            f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;
-            if (qvalid) {
-                const float* src = qkv_b + (long)lq * C3 + ch0 + 8 * kq;
-                q0 = *reinterpret_cast<const f32x4*>(src);
-                q1 = *reinterpret_cast<const f32x4*>(src + 4);
+            f32x4 q0 = q0_pre, q1 = q1_pre;
+            if (qt != wave) {                       // only when a wave owns more than one query tile (N > 128)
+                q0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                q1 = q0;
+                lq = qvalid ? token_of(br, w, p.reso, tq) : 0;
+                if (qvalid) {
+                    const float* src = qkv_b + (long)lq * C3 + ch0 + 8 * kq;
+                    q0 = *reinterpret_cast<const f32x4*>(src);
+                    q1 = *reinterpret_cast<const f32x4*>(src + 4);
+                }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -207,6 +225,16 @@ __global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnPa
 // =====================================================================================
 // backward
 // =====================================================================================
+// sum over the 16 lanes of a DPP row (the lanes that share lane >> 4); every lane of the row gets the total.
+// row_ror:n rotates within a row of 16 lanes: pure VALU, no LDS crossbar (ds_bpermute) round trips.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+
 template <int NT>
 __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
     constexpr int NP = 16 * NT;
@@ -292,11 +320,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
         for (int r = 0; r < 4; ++r) {
             const float pv = kvalid ? __expf(sa[r] * p.scale - ls[r]) : 0.f;
             sa[r] = pv;
-            float t = pv * da[r];
-            t += __shfl_xor(t, 1, 64);
-            t += __shfl_xor(t, 2, 64);
-            t += __shfl_xor(t, 4, 64);
-            t += __shfl_xor(t, 8, 64);
+            const float t = row16_sum(pv * da[r]);
             if (li == 0) atomicAdd(&del_s[16 * qt + 4 * kq + r], t);
         }
         P[qt] = sa;
@@ -407,19 +431,26 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
 }
 
 // dw[cb][tap] / db[cb] = sum over (b, window) of the partial slabs.  One workgroup per (head, tap-or-bias).
-__global__ __launch_bounds__(256) void lepe_grad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                                float* __restrict__ db, int heads, int nslab) {
-    __shared__ float red[256];
+__global__ __launch_bounds__(1024) void lepe_grad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                 float* __restrict__ db, int heads, int nslab) {
+    __shared__ float red[1024];
     const int g = blockIdx.x / 10, i = blockIdx.x - g * 10;
     const int d = threadIdx.x & 31, sg = threadIdx.x >> 5;
-    float s = 0.f;
-    for (int sl = sg; sl < nslab; sl += 8) s += part[((long)sl * heads + g) * 10 * HD + i * HD + d];
-    red[threadIdx.x] = s;
+    const long stride = (long)heads * 10 * HD;
+    const float* base = part + (long)g * 10 * HD + i * HD + d;
+    float s0 = 0.f, s1 = 0.f;
+    int sl = sg;
+    for (; sl + 32 < nslab; sl += 64) {
+        s0 += base[sl * stride];
+        s1 += base[(sl + 32) * stride];
+    }
+    if (sl < nslab) s0 += base[sl * stride];
+    red[threadIdx.x] = s0 + s1;
     __syncthreads();
     if (threadIdx.x < 32) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k * 32 + d];
+        for (int k = 0; k < 32; ++k) t += red[k * 32 + d];
         const int cb = g * HD + d;
         if (i < 9) dw[cb * 9 + i] = t;
         else db[cb] = t;
@@ -600,7 +631,7 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* ls
     CSWIN_LAUNCH_CHECK();
     for (int i = 0; i < nbranch; ++i) {
         const AttnBranch& br = p.br[i];
-        hipLaunchKernelGGL(lepe_grad_reduce_kernel, dim3(br.heads * 10), dim3(256), 0, st, br.dw_part, dlepe_w[i],
+        hipLaunchKernelGGL(lepe_grad_reduce_kernel, dim3(br.heads * 10), dim3(1024), 0, st, br.dw_part, dlepe_w[i],
                            dlepe_b[i], br.heads, B * br.nWin);
     }
     CSWIN_LAUNCH_CHECK();

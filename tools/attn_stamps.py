@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""In-kernel timeline of attn_bwd: attn_stamps.py stage(1..4) [batch]"""
+import os, sys, ctypes
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cswin_unet_amd._lib import call, lib, ptr, stream
+si = int(sys.argv[1]) - 1; batch = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+E, heads, split = 64, [2, 4, 8, 16], [1, 2, 7, 7]
+C, reso = E << si, 56 >> si; L = reso * reso
+single = si == 3
+idx = [-1] if single else [0, 1]; hb = [heads[si]] if single else [heads[si] // 2] * 2
+nb, cb = len(idx), C // len(idx)
+dev = "cuda"
+qkv = torch.randn(batch, L, 3 * C, device=dev); w = [torch.randn(cb, 9, device=dev) / 3 for _ in idx]; b = [torch.randn(cb, device=dev) * .02 for _ in idx]
+dy = torch.randn(batch, L, C, device=dev); y = torch.empty(batch, L, C, device=dev); lse = torch.empty(batch, sum(hb), L, device=dev)
+dqkv = torch.empty_like(qkv); dw = [torch.empty_like(t) for t in w]; db = [torch.empty_like(t) for t in b]
+ia, ha = (ctypes.c_int * nb)(*idx), (ctypes.c_int * nb)(*hb)
+pa = lambda ts: (ctypes.c_void_p * nb)(*[t.data_ptr() for t in ts])
+nbytes = lib().cswin_attn_bwd_workspace(batch, reso, C, nb, ha, ia, split[si]); ws = torch.empty(nbytes // 4 + 4, device=dev)
+call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(lse), batch, reso, C, nb, ha, ia, split[si], 0.0, stream())
+def bwd(): call("cswin_attn_bwd", ptr(qkv), pa(w), ptr(lse), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws), nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, stream())
+for _ in range(3): bwd()
+torch.cuda.synchronize()
+st = torch.zeros(1 << 16, 8, dtype=torch.int64, device=dev)
+h = lib(); h.cswin_debug_set_attn_stamps.argtypes = [ctypes.c_void_p]
+h.cswin_debug_set_attn_stamps(ctypes.c_void_p(st.data_ptr())); bwd(); torch.cuda.synchronize(); h.cswin_debug_set_attn_stamps(None)
+s = st.cpu().numpy(); s = s[s[:, 0] != 0]
+print(f"stage {si+1}: {len(s)} workgroups")
+names = ["P0 load->LDS", "P1 frags+lepe wgrad", "P2 loop1 (S,dP,delta)", "P3 loop2 (dV,dK,dS,dQ)", "barrier", "P4 dQ store"]
+for k, nm in enumerate(names):
+    d = s[:, k + 1] - s[:, k]
+    print(f"  {nm:20s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f} cycles")
+d = s[:, 6] - s[:, 0]; print(f"  {'total':20s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f}")
