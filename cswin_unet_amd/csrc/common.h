@@ -55,21 +55,23 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
-// out[i] = sum_r part[r * stride + i], i < n  (deterministic order).  32 columns x 8 row-groups per workgroup so that
+// out[i] = sum_r part[r * stride + i], i < n  (deterministic order).  32 columns x G row-groups per workgroup so that
 // partial-slab reductions (split-K weight gradients, LayerNorm dgamma/dbeta, loss sums, bias sums) are parallel over
-// the slabs instead of one serial chain per column.  Columns >= n_first go to out2[i - n_first] when out2 != NULL.
-static __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                               float* __restrict__ out2, long n_first, long n, int rows,
-                                                               long stride) {
-    __shared__ float red[8][33];
+// the slabs instead of one serial chain per column (G = 8 for few slabs, 32 for many; two loads in flight per thread).
+// Columns >= n_first go to out2[i - n_first] when out2 != NULL.
+template <int G>
+static __global__ __launch_bounds__(32 * G) void rows_sum_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                  float* __restrict__ out2, long n_first, long n, int rows,
+                                                                  long stride) {
+    __shared__ float red[G][33];
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     const long i = (long)blockIdx.x * 32 + c;
     float s0 = 0.f, s1 = 0.f;
     if (i < n) {
         int r = g;
-        for (; r + 8 < rows; r += 16) {
+        for (; r + G < rows; r += 2 * G) {
             s0 += part[(long)r * stride + i];
-            s1 += part[(long)(r + 8) * stride + i];
+            s1 += part[(long)(r + G) * stride + i];
         }
         if (r < rows) s0 += part[(long)r * stride + i];
     }
@@ -78,7 +80,7 @@ static __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __res
     if (g == 0 && i < n) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][c];
+        for (int k = 0; k < G; ++k) t += red[k][c];
         if (out2 && i >= n_first) out2[i - n_first] = t;
         else out[i] = t;
     }
@@ -86,5 +88,9 @@ static __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __res
 
 static inline void launch_rows_sum(const float* part, float* out, float* out2, long n_first, long n, int rows, long stride,
                                    hipStream_t st) {
-    hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, part, out, out2, n_first, n, rows, stride);
+    const unsigned blocks = (unsigned)((n + 31) / 32);
+    if (rows > 48)
+        hipLaunchKernelGGL(rows_sum_kernel<32>, dim3(blocks), dim3(1024), 0, st, part, out, out2, n_first, n, rows, stride);
+    else
+        hipLaunchKernelGGL(rows_sum_kernel<8>, dim3(blocks), dim3(256), 0, st, part, out, out2, n_first, n, rows, stride);
 }

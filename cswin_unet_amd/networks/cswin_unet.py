@@ -105,9 +105,14 @@ class CSWinBlock(nn.Module):
         self.norm2 = norm_layer(dim)
 
     def _keep_scale(self, x):
-        """Per-sample DropPath factor (mask / keep_prob) or None; one draw per residual branch like the reference."""
+        """Per-sample DropPath factor (mask / keep_prob) or None; one draw per residual branch like the reference.
+        CSWinTransformer pre-draws the factors of ALL blocks in one launch (self._dp_preset) to avoid 2 tiny RNG
+        launches per block; a block used on its own draws them itself."""
         dp = self.drop_path
         if isinstance(dp, DropPath) and self.training and dp.drop_prob > 0.:
+            preset = getattr(self, "_dp_preset", None)
+            if preset:
+                return preset.pop(0)
             return dp.sample_scale(x.shape[0], x.device)
         return None
 
@@ -267,8 +272,29 @@ class CSWinTransformer(nn.Module):
             x = checkpoint.checkpoint(blk, x, use_reentrant=False) if self.use_chk else blk(x)
         return x
 
+    def _predraw_drop_path(self, batch, device):
+        """One Bernoulli launch for the stochastic-depth factors of every block (2 per block: attention and MLP branch)."""
+        blocks = [b for st in (self.stage1, self.stage2, self.stage3, self.stage4, self.stage_up4, self.stage_up3,
+                               self.stage_up2, self.stage_up1) for b in st]
+        live = [b for b in blocks if isinstance(b.drop_path, DropPath) and b.drop_path.drop_prob > 0.]
+        for b in blocks:
+            b._dp_preset = None
+        if not (self.training and live):
+            return
+        cache = getattr(self, "_dp_keep", None)
+        if cache is None or cache.device != device or cache.shape[0] != 2 * len(live):
+            # built once, outside any hipGraph capture (the first training forward is an eager warm-up)
+            cache = torch.tensor([1.0 - b.drop_path.drop_prob for b in live for _ in (0, 1)], dtype=torch.float32,
+                                 device=device)[:, None]
+            self._dp_keep = cache
+        keep = cache
+        scales = (torch.rand(keep.shape[0], batch, device=device) < keep).to(torch.float32) / keep
+        for i, b in enumerate(live):
+            b._dp_preset = [scales[2 * i], scales[2 * i + 1]]
+
     # encoder and bottleneck
     def forward_features(self, x):
+        self._predraw_drop_path(x.shape[0], x.device)
         x = self.stage1_conv_embed(x)
         if self.pos_drop.p > 0 and self.training:
             raise NotImplementedError("pos_drop p > 0 is not implemented on the HIP path (reference config uses 0)")

@@ -16,6 +16,55 @@ __all__ = ["layer_norm", "linear", "mlp", "stripe_attention", "conv_tokens", "pa
            "tokens_to_nchw", "matmul_nn", "ce_dice_loss", "img2windows", "windows2img"]
 
 
+# ------------------------------------------------------------------------------------------------
+# weight-gradient side stream
+# ------------------------------------------------------------------------------------------------
+# In backward, a layer's weight gradient (split-K GEMM + slab reduction) is independent of the data-gradient chain that
+# the next layer waits for.  When enabled (HipEngine does; default off so that `loss.backward(); torch.optim.step()`
+# stays a plain single-stream program), weight-gradient launches go to a second HIP stream forked from the current
+# one, so the two chains fill each other's launch ramps and tails (every kernel of this model is 10-50 us).  The fork /
+# join edges are ordinary events, so the same code is captured into hipGraphs as parallel branches.
+_overlap = {"on": False, "stream": None, "pending": []}
+
+
+def set_wgrad_overlap(enabled: bool):
+    _overlap["on"] = bool(enabled)
+
+
+class _side_stream:
+    """with _side_stream(*tensors): launches inside go to the side stream, ordered after everything already enqueued
+    on the current stream; `tensors` (inputs living on the main stream's allocator) are kept alive until
+    join_wgrad_stream() so the caching allocator cannot recycle them under the side stream."""
+
+    def __init__(self, *keep):
+        self.keep = keep
+
+    def __enter__(self):
+        if not _overlap["on"]:
+            self.ctx = None
+            return self
+        if _overlap["stream"] is None:
+            _overlap["stream"] = torch.cuda.Stream()
+        side = _overlap["stream"]
+        side.wait_stream(torch.cuda.current_stream())
+        _overlap["pending"].append(self.keep)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def join_wgrad_stream():
+    """Make the current stream wait for every weight gradient launched on the side stream (call before reading .grad)."""
+    if _overlap["stream"] is not None and _overlap["pending"]:
+        torch.cuda.current_stream().wait_stream(_overlap["stream"])
+    _overlap["pending"].clear()
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16) // 4 + 4, dtype=torch.float32, device=device)
 
@@ -106,12 +155,13 @@ class _Linear(Function):
             call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), ptr(dx2), K1 if x2 is not None else 0, None,
                  ptr(row_scale), ctx.rps, None, M, N, K, stream())
         if need[1]:
-            dw = torch.empty_like(w)
-            db = torch.empty(N, dtype=torch.float32, device=w.device) if ctx.has_bias else None
-            nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
-            ws = _ws(nbytes, w.device)
-            call("cswin_linear_bwd_weight", ptr(dy), ptr(x), ptr(x2), K1 if x2 is not None else 0, ptr(row_scale), ctx.rps,
-                 ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, stream())
+            with _side_stream(dy, x, x2, row_scale):
+                dw = torch.empty_like(w)
+                db = torch.empty(N, dtype=torch.float32, device=w.device) if ctx.has_bias else None
+                nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
+                ws = _ws(nbytes, w.device)
+                call("cswin_linear_bwd_weight", ptr(dy), ptr(x), ptr(x2), K1 if x2 is not None else 0, ptr(row_scale), ctx.rps,
+                     ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, stream())
         dres = dy if ctx.has_res else None
         return dx, dw, db, dx2, dres, None
 
@@ -156,19 +206,21 @@ class _Mlp(Function):
         dpre = torch.empty_like(pre)
         call("cswin_linear_bwd_data", ptr(dy), ptr(w2), ptr(dpre), None, 0, ptr(pre), ptr(row_scale), ctx.rps, None, M, N,
              Hd, st)
-        dw2 = torch.empty_like(w2)
-        db2 = torch.empty(N, dtype=torch.float32, device=dev) if ctx.has_b2 else None
-        nbytes = max(lib().cswin_linear_bwd_weight_workspace(M, N, Hd), lib().cswin_linear_bwd_weight_workspace(M, Hd, K))
-        ws = _ws(nbytes, dev)
-        call("cswin_linear_bwd_weight", ptr(dy), ptr(act), None, 0, ptr(row_scale), ctx.rps, ptr(dw2), ptr(db2), ptr(ws),
-             nbytes, M, N, Hd, st)
-        dw1 = torch.empty_like(w1)
-        db1 = torch.empty(Hd, dtype=torch.float32, device=dev) if ctx.has_b1 else None
-        call("cswin_linear_bwd_weight", ptr(dpre), ptr(x), None, 0, None, 1, ptr(dw1), ptr(db1), ptr(ws), nbytes, M, Hd, K, st)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             call("cswin_linear_bwd_data", ptr(dpre), ptr(w1), ptr(dx), None, 0, None, None, 1, None, M, Hd, K, st)
+        with _side_stream(dy, act, dpre, x, row_scale):          # both weight gradients, off the data-gradient chain
+            dw2 = torch.empty_like(w2)
+            db2 = torch.empty(N, dtype=torch.float32, device=dev) if ctx.has_b2 else None
+            nbytes = max(lib().cswin_linear_bwd_weight_workspace(M, N, Hd), lib().cswin_linear_bwd_weight_workspace(M, Hd, K))
+            ws = _ws(nbytes, dev)
+            call("cswin_linear_bwd_weight", ptr(dy), ptr(act), None, 0, ptr(row_scale), ctx.rps, ptr(dw2), ptr(db2), ptr(ws),
+                 nbytes, M, N, Hd, stream())
+            dw1 = torch.empty_like(w1)
+            db1 = torch.empty(Hd, dtype=torch.float32, device=dev) if ctx.has_b1 else None
+            call("cswin_linear_bwd_weight", ptr(dpre), ptr(x), None, 0, None, 1, ptr(dw1), ptr(db1), ptr(ws), nbytes, M, Hd, K,
+                 stream())
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None
 
 
@@ -296,14 +348,15 @@ class _ConvTokens(Function):
             _, wpt = _permute_w(w, Cin, True)
             dx = torch.empty_like(x)
             call("cswin_conv_tok_bwd_data", ptr(dy), ptr(wpt), ptr(dx), B, H, W, Cin, Cout, ks, stride, pad, st)
-        dwp = torch.empty(Cout, ks * ks, Cin, dtype=torch.float32, device=x.device)
-        db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_b else None
-        nbytes = lib().cswin_conv_tok_bwd_weight_workspace(B, H, W, Cin, Cout, ks, stride, pad)
-        ws = _ws(nbytes, x.device)
-        call("cswin_conv_tok_bwd_weight", ptr(dy), ptr(x), ptr(dwp), ptr(db), ptr(ws), nbytes, B, H, W, Cin, Cout, ks, stride,
-             pad, st)
-        dw = torch.empty_like(w)
-        call("cswin_conv_weight_unpermute", ptr(dwp), ptr(dw), Cout, Cin, ks, Cin, st)
+        with _side_stream(dy, x):
+            dwp = torch.empty(Cout, ks * ks, Cin, dtype=torch.float32, device=x.device)
+            db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_b else None
+            nbytes = lib().cswin_conv_tok_bwd_weight_workspace(B, H, W, Cin, Cout, ks, stride, pad)
+            ws = _ws(nbytes, x.device)
+            call("cswin_conv_tok_bwd_weight", ptr(dy), ptr(x), ptr(dwp), ptr(db), ptr(ws), nbytes, B, H, W, Cin, Cout, ks,
+                 stride, pad, stream())
+            dw = torch.empty_like(w)
+            call("cswin_conv_weight_unpermute", ptr(dwp), ptr(dw), Cout, Cin, ks, Cin, stream())
         return dx, dw, db, None, None, None, None
 
 

@@ -81,6 +81,8 @@ class FlatSGD:
 
     def gather_grads(self):
         """Pack every p.grad into self.flat_grad (one launch)."""
+        from .ops import join_wgrad_stream
+        join_wgrad_stream()          # weight gradients may have been produced on the side stream
         t = self._gather_table()
         call("cswin_multi_copy", ptr(t), t.shape[0], stream())
         return self.flat_grad

@@ -71,6 +71,8 @@ class HipEngine:
         self.stats = torch.zeros(3, dtype=torch.float32, device=dev)          # [loss, ce, dice] of the last step
         self._coef = torch.zeros(2 * num_classes, dtype=torch.float32, device=dev)
         self.use_graph, self._graphs, self._logits = use_graph, None, None
+        from . import ops
+        ops.set_wgrad_overlap(os.environ.get("CSWIN_WGRAD_OVERLAP", "0") != "0")
 
     # flat views the protocol all-reduces / broadcasts
     @property
