@@ -123,14 +123,14 @@ class CSWinBlock(nn.Module):
         if self.proj_drop.p > 0 and self.training:
             raise NotImplementedError("proj dropout p > 0 is not implemented on the HIP path (reference uses 0)")
         a = self.attns
-        h = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        qkv = ops.linear(h, self.qkv.weight, self.qkv.bias)
-        att = ops.stripe_attention(qkv, self.patches_resolution, self.split_size, [m.idx for m in a],
-                                   [m.num_heads for m in a], [m.get_v.weight for m in a], [m.get_v.bias for m in a],
-                                   a[0].scale)
-        x = ops.linear(att, self.proj.weight, self.proj.bias, residual=x, row_scale=self._keep_scale(x))
-        h = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        return self.mlp(h, residual=x, row_scale=self._keep_scale(x))
+        if self.mlp.drop.p > 0 and self.training:
+            raise NotImplementedError("Mlp dropout p > 0 is not implemented on the HIP path (reference uses 0)")
+        if type(self.norm1) is not nn.LayerNorm or type(self.norm2) is not nn.LayerNorm:
+            raise NotImplementedError("the HIP block fuses nn.LayerNorm only")
+        rs1, rs2 = self._keep_scale(x), self._keep_scale(x)
+        return ops.cswin_block(x, self.patches_resolution, self.split_size, [m.idx for m in a], [m.num_heads for m in a],
+                               a[0].scale, self.norm1, self.qkv, self.proj, self.norm2, self.mlp.fc1, self.mlp.fc2,
+                               [m.get_v.weight for m in a], [m.get_v.bias for m in a], rs1, rs2)
 
 
 def img2windows(img, H_sp, W_sp):

@@ -12,7 +12,7 @@ from torch.autograd.function import once_differentiable
 
 from ._lib import call, dev_f32, lib, ptr, stream
 
-__all__ = ["layer_norm", "linear", "mlp", "stripe_attention", "conv_tokens", "patch_embed_conv", "carafe_reassemble",
+__all__ = ["layer_norm", "linear", "mlp", "stripe_attention", "cswin_block", "conv_tokens", "patch_embed_conv", "carafe_reassemble",
            "tokens_to_nchw", "matmul_nn", "ce_dice_loss", "img2windows", "windows2img"]
 
 
@@ -306,6 +306,109 @@ class _StripeAttention(Function):
 def stripe_attention(qkv, reso, split, idx, heads, lepe_w, lepe_b, scale=None):
     """qkv (B, L, 3C) -> (B, L, C).  idx/heads/lepe_w/lepe_b: one entry per branch."""
     return _StripeAttention.apply(qkv, reso, split, tuple(idx), tuple(heads), scale, *lepe_w, *lepe_b)
+
+
+# ------------------------------------------------------------------------------------------------
+# whole CSWinBlock as ONE autograd node
+# ------------------------------------------------------------------------------------------------
+class _CSWinBlock(Function):
+    """x -> x + dp1(proj(attn(qkv(LN1 x)))) -> ... + dp2(fc2(gelu(fc1(LN2 .))))  (cswin_unet.py:160-181).
+
+    Same kernels as the fine-grained ops; as one node the backward chains them by hand, so the two residual-fork
+    gradient sums are the `dres` input of the LayerNorm backward kernel (no aten::add), and 14 autograd nodes per
+    block become one."""
+
+    @staticmethod
+    def forward(ctx, x, reso, split, idx, heads, scale, eps1, eps2, rs1, rs2, g1, b1, wqkv, bqkv, wp, bp, g2, b2, w1, bb1,
+                w2, bb2, *lepe):
+        x = dev_f32(x, "block input")
+        B, L, C = x.shape
+        if L != reso * reso:
+            raise ValueError("flatten img_tokens has wrong size")
+        M = B * L
+        dev, st = x.device, stream()
+        nb = len(idx)
+        lw = [dev_f32(t).view(t.shape[0], 9) for t in lepe[:nb]]
+        lb = [dev_f32(t) for t in lepe[nb:]]
+        rs1, rs2 = dev_f32(rs1), dev_f32(rs2)
+        E = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        h1, m1, r1 = torch.empty_like(x), E(M), E(M)
+        call("cswin_layernorm_fwd", ptr(x), ptr(g1), ptr(b1), ptr(h1), ptr(m1), ptr(r1), M, C, eps1, st)
+        qkv = E(B, L, 3 * C)
+        call("cswin_linear_fwd", ptr(h1), None, 0, ptr(wqkv), ptr(bqkv), ptr(qkv), None, None, None, 1, M, 3 * C, C, st)
+        att, lse = E(B, L, C), E(B, sum(heads), L)
+        ha, ia = _int_array(heads), _int_array(idx)
+        call("cswin_attn_fwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(att), ptr(lse), B, reso, C, nb, ha, ia, split,
+             float(scale or 0.0), st)
+        x1 = torch.empty_like(x)
+        call("cswin_linear_fwd", ptr(att), None, 0, ptr(wp), ptr(bp), ptr(x1), None, ptr(x), ptr(rs1), L, M, C, C, st)
+        h2, m2, r2 = torch.empty_like(x), E(M), E(M)
+        call("cswin_layernorm_fwd", ptr(x1), ptr(g2), ptr(b2), ptr(h2), ptr(m2), ptr(r2), M, C, eps2, st)
+        Hd = w1.shape[0]
+        pre, act = E(B, L, Hd), E(B, L, Hd)
+        call("cswin_linear_fwd", ptr(h2), None, 0, ptr(w1), ptr(bb1), ptr(pre), ptr(act), None, None, 1, M, Hd, C, st)
+        y = torch.empty_like(x)
+        call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(bb2), ptr(y), None, ptr(x1), ptr(rs2), L, M, C, Hd, st)
+        ctx.save_for_backward(x, m1, r1, h1, qkv, lse, att, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lw)
+        ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0), bqkv is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (x, m1, r1, h1, qkv, lse, att, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lw) = ctx.saved_tensors
+        reso, split, idx, heads, scale, has_qkv_bias = ctx.meta
+        dy = dev_f32(dy)
+        B, L, C = x.shape
+        M, Hd, nb = B * L, w1.shape[0], len(idx)
+        dev, st, h = x.device, stream(), lib()
+        E = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        nws = max(h.cswin_linear_bwd_weight_workspace(M, C, Hd), h.cswin_linear_bwd_weight_workspace(M, Hd, C),
+                  h.cswin_linear_bwd_weight_workspace(M, 3 * C, C), h.cswin_layernorm_bwd_workspace(M, C))
+        ws = _ws(nws, dev)
+        # ---- MLP branch ----
+        dpre = torch.empty_like(pre)
+        call("cswin_linear_bwd_data", ptr(dy), ptr(w2), ptr(dpre), None, 0, ptr(pre), ptr(rs2), L, None, M, C, Hd, st)
+        dw2, db2 = torch.empty_like(w2), E(C)
+        call("cswin_linear_bwd_weight", ptr(dy), ptr(act), None, 0, ptr(rs2), L, ptr(dw2), ptr(db2), ptr(ws), nws, M, C, Hd, st)
+        dw1, db1 = torch.empty_like(w1), E(Hd)
+        call("cswin_linear_bwd_weight", ptr(dpre), ptr(h2), None, 0, None, 1, ptr(dw1), ptr(db1), ptr(ws), nws, M, Hd, C, st)
+        dh2 = torch.empty_like(x)
+        call("cswin_linear_bwd_data", ptr(dpre), ptr(w1), ptr(dh2), None, 0, None, None, 1, None, M, Hd, C, st)
+        dx1, dg2, dbt2 = torch.empty_like(x), E(C), E(C)
+        call("cswin_layernorm_bwd", ptr(dh2), ptr(x1), ptr(m2), ptr(r2), ptr(g2), ptr(dy), ptr(dx1), ptr(dg2), ptr(dbt2), ptr(ws),
+             nws, M, C, st)
+        # ---- attention branch ----
+        datt = dh2                                                     # reuse
+        call("cswin_linear_bwd_data", ptr(dx1), ptr(wp), ptr(datt), None, 0, None, ptr(rs1), L, None, M, C, C, st)
+        dwp, dbp = torch.empty_like(wp), E(C)
+        call("cswin_linear_bwd_weight", ptr(dx1), ptr(att), None, 0, ptr(rs1), L, ptr(dwp), ptr(dbp), ptr(ws), nws, M, C, C, st)
+        dqkv = torch.empty_like(qkv)
+        dlw = [torch.empty_like(t) for t in lw]
+        dlb = [E(t.shape[0]) for t in lw]
+        ha, ia = _int_array(heads), _int_array(idx)
+        naw = h.cswin_attn_bwd_workspace(B, reso, C, nb, ha, ia, split)
+        aws = _ws(naw, dev)
+        call("cswin_attn_bwd", ptr(qkv), _ptr_array(lw), ptr(lse), ptr(datt), ptr(dqkv), _ptr_array(dlw), _ptr_array(dlb),
+             ptr(aws), naw, B, reso, C, nb, ha, ia, split, scale, st)
+        dwqkv = torch.empty_like(wqkv)
+        dbqkv = E(3 * C) if has_qkv_bias else None
+        call("cswin_linear_bwd_weight", ptr(dqkv), ptr(h1), None, 0, None, 1, ptr(dwqkv), ptr(dbqkv), ptr(ws), nws, M, 3 * C, C, st)
+        dh1 = datt                                                     # reuse again
+        call("cswin_linear_bwd_data", ptr(dqkv), ptr(wqkv), ptr(dh1), None, 0, None, None, 1, None, M, 3 * C, C, st)
+        dx, dg1, dbt1 = torch.empty_like(x), E(C), E(C)
+        call("cswin_layernorm_bwd", ptr(dh1), ptr(x), ptr(m1), ptr(r1), ptr(g1), ptr(dx1), ptr(dx), ptr(dg1), ptr(dbt1), ptr(ws),
+             nws, M, C, st)
+        grads = (dx, None, None, None, None, None, None, None, None, None, dg1, dbt1, dwqkv, dbqkv, dwp, dbp, dg2, dbt2, dw1, db1,
+                 dw2, db2)
+        return grads + tuple(d.view(d.shape[0], 1, 3, 3) for d in dlw) + tuple(dlb)
+
+
+def cswin_block(x, reso, split, idx, heads, scale, norm1, qkv, proj, norm2, fc1, fc2, lepe_w, lepe_b, rs1=None, rs2=None):
+    """Fused CSWinBlock forward/backward.  norm*/qkv/proj/fc*: nn.Modules holding the parameters."""
+    return _CSWinBlock.apply(x, reso, split, tuple(idx), tuple(heads), scale, norm1.eps, norm2.eps, rs1, rs2,
+                             norm1.weight, norm1.bias, qkv.weight, qkv.bias, proj.weight, proj.bias, norm2.weight,
+                             norm2.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, *lepe_w, *lepe_b)
 
 
 # ------------------------------------------------------------------------------------------------
