@@ -112,6 +112,49 @@ struct ConvTSrc {
     }
 };
 
+// Stride-2 3x3 pad-1 data gradient, one input-pixel parity class (py, px) at a time: an input pixel only ever meets the
+// taps with ky = (iy + 1) mod 2 (+2), kx likewise, i.e. 1, 2, 2 or 4 of the 9 taps depending on its class.  Gathering
+// over all 9 taps (ConvTSrc) feeds 75 % structural zeros to the MFMAs; per class there are none.
+// i = class-local pixel (b, jy, jx) <-> (iy, ix) = (2 jy + py, 2 jx + px);  j = tap_local * C + co.
+struct ConvTS2Src {
+    const float* dy; int B, H, W, C, OH, OW, py, px, H2, W2, kys, kxs; int rows, cols;   // kys/kxs: 2 bits per local tap
+    struct Row { int b, iy, ix; float s; };
+    __device__ Row row(int i) const {
+        Row r;
+        r.s = 1.0f;
+        if (i >= rows) { r.b = -1; r.iy = r.ix = 0; return r; }
+        const int hw = H2 * W2;
+        r.b = i / hw;
+        const int rem = i - r.b * hw;
+        const int jy = rem / W2;
+        r.iy = 2 * jy + py;
+        r.ix = 2 * (rem - jy * W2) + px;
+        return r;
+    }
+    __device__ const float* ptr(const Row& r, int j) const {
+        if (r.b < 0 || j >= cols) return nullptr;
+        const int t = j / C, co = j - t * C;
+        const int oy = (r.iy + 1 - ((kys >> (2 * t)) & 3)) >> 1, ox = (r.ix + 1 - ((kxs >> (2 * t)) & 3)) >> 1;
+        if (oy >= OH || ox >= OW) return nullptr;
+        return dy + ((long)(r.b * OH + oy) * OW + ox) * C + co;
+    }
+};
+
+// rows (tap_local, co) of the [9][Cout][Cin] weight image that belong to one parity class
+struct TapRowsSrc {
+    const float* w; int Cout, Cin, taps; int rows, cols;      // taps: 4 bits per local tap (index into the 9 taps)
+    struct Row { const float* base; float s; };
+    __device__ Row row(int i) const {
+        Row r;
+        r.s = 1.0f;
+        if (i >= rows) { r.base = nullptr; return r; }
+        const int t = i / Cout, co = i - t * Cout;
+        r.base = w + ((long)((taps >> (4 * t)) & 15) * Cout + co) * Cin;
+        return r;
+    }
+    __device__ const float* ptr(const Row& r, int j) const { return (r.base && j < cols) ? r.base + j : nullptr; }
+};
+
 // ------------------------------------------------------------------------------------
 // epilogue
 // ------------------------------------------------------------------------------------
@@ -127,8 +170,9 @@ struct Epilogue {
     const float* gelu_pre; long ldpre;        // EPI_GELUBWD: C = row_scale * acc * gelu'(gelu_pre[m][n])
     long split_stride;                        // C += split * split_stride (split-R partial slabs)
     float* colsum; int colsum_stride;         // TN only: partial column sums of A (dbias), [split][M]
+    int rm_on, rm_H, rm_W, rm_H2, rm_W2, rm_py, rm_px;   // output row m is a parity-class pixel index -> full (b, iy, ix) row
     int vec_store;                            // 1: every output / auxiliary row is 16-B aligned and N % 4 == 0
-    long long* stamps;                        // debug: per-workgroup s_memtime stamps [nblk][4] (NULL in production)
+    long long* stamps;                        // debug: per-workgroup s_memtime stamps [nblk][8] (NULL in production)
 };
 
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), i.e. a lane owns one
@@ -145,6 +189,12 @@ __device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[FM
     const int li = lane & 31, lh = lane >> 5;
     const int rrow = lane >> 3, rcol = (lane & 7) * 4;
     const bool has_rs = e.row_scale != nullptr;
+    auto out_row = [&](int m) -> long {           // class-local pixel -> row of the full (B, H*W, C) token matrix
+        if (!e.rm_on) return m;
+        const int hw = e.rm_H2 * e.rm_W2;
+        const int b = m / hw, rem = m - b * hw, jy = rem / e.rm_W2;
+        return ((long)b * e.rm_H + 2 * jy + e.rm_py) * e.rm_W + 2 * (rem - jy * e.rm_W2) + e.rm_px;
+    };
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -186,7 +236,7 @@ __device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[FM
                     if (EPI == EPI_SPLIT2 && n >= e.col_split)
                         *reinterpret_cast<f32x4*>(e.C2 + (long)m * e.ldc2 + (n - e.col_split)) = o;
                     else
-                        *reinterpret_cast<f32x4*>(e.C + (long)m * e.ldc + n) = o;
+                        *reinterpret_cast<f32x4*>(e.C + out_row(m) * e.ldc + n) = o;
                     if (EPI == EPI_ACT) {
                         f32x4 a;
 #pragma unroll
@@ -209,7 +259,7 @@ __device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[FM
                         o *= rsv;
                         if (EPI == EPI_RES) o += e.residual[(long)m * e.ldres + nn];
                         if (EPI == EPI_SPLIT2 && nn >= e.col_split) e.C2[(long)m * e.ldc2 + (nn - e.col_split)] = o;
-                        else e.C[(long)m * e.ldc + nn] = o;
+                        else e.C[out_row(m) * e.ldc + nn] = o;
                         if (EPI == EPI_ACT) e.Cact[(long)m * e.ldact + nn] = gelu_f(o);
                     }
                 }
@@ -224,8 +274,12 @@ __device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[FM
 // the kernel
 // ------------------------------------------------------------------------------------
 // SCALE_A: multiply the A operand rows by their Row::s (DropPath factor) when staging (weight gradients only)
-template <int BM, int BN, int BK, bool A_RC, bool B_RC, int VEC, int EPI, bool SCALE_A, class ASrc, class BSrc>
-__global__ __launch_bounds__(256) void gemm_kernel(ASrc A, BSrc B, Epilogue epi, int M, int N, int R,
+// KW: wave groups that split each reduction tile between them (workgroup = 4*KW waves; group g multiplies the k-slice
+// [g*BK/KW, (g+1)*BK/KW) of every tile, the groups' accumulators are summed through LDS at the end).  When M*N is too
+// small to give every SIMD >= 2 independent MFMA chains (stage-3/4 shapes with long K) this doubles / quadruples the
+// resident waves per workgroup without a global split-K reduction.
+template <int BM, int BN, int BK, int KW, bool A_RC, bool B_RC, int VEC, int EPI, bool SCALE_A, class ASrc, class BSrc>
+__global__ __launch_bounds__(256 * KW) void gemm_kernel(ASrc A, BSrc B, Epilogue epi, int M, int N, int R,
                                                     int r_per_split, int tiles_m, int tiles_n) {
     constexpr int WM = BM / 2, WN = BN / 2;          // 4 waves as 2 x 2
     constexpr int FM = WM / 32, FN = WN / 32;        // 32x32 fragments per wave
@@ -239,7 +293,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(ASrc A, BSrc B, Epilogue epi,
     float* As = lds;
     float* Bs = lds + A_ELEMS;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NTH = 256 * KW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, kg = tid >> 8;
     const int li = lane & 31, lh = lane >> 5;
     // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so give every XCD a
     // CONTIGUOUS range of logical blocks, ordered [split][m-tile][n-tile]: the blocks that re-read one A row panel
@@ -256,10 +311,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(ASrc A, BSrc B, Epilogue epi,
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
 
     // loader geometry
-    constexpr int QA = BM * BK / 1024, QB = BN * BK / 1024; // chunks (16 B) per thread per tile
+    constexpr int QA = BM * BK / (4 * NTH), QB = BN * BK / (4 * NTH); // chunks (16 B) per thread per tile
+    static_assert(QA >= 1 && QB >= 1 && (BK / KW) % 8 == 0, "tile too small for this many wave groups");
     constexpr int A_CPR = A_RC ? BK / 4 : BM / 4;           // chunks per LDS row
     constexpr int B_CPR = B_RC ? BK / 4 : BN / 4;
-    constexpr int A_RPP = 256 / A_CPR, B_RPP = 256 / B_CPR; // rows per pass
+    constexpr int A_RPP = NTH / A_CPR, B_RPP = NTH / B_CPR; // rows per pass
     const int a_c = tid % A_CPR, a_r = tid / A_CPR;
     const int b_c = tid % B_CPR, b_r = tid / B_CPR;
 
@@ -352,12 +408,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(ASrc A, BSrc B, Epilogue epi,
     float csum = 0.f;   // dbias partial (TN, A row-contiguous image: column tid of the A tile)
     const bool do_colsum = !A_RC && epi.colsum && n0 == 0 && tid < BM;
 
-    if (epi.stamps && tid == 0) epi.stamps[4L * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
+    if (epi.stamps && tid == 0) { epi.stamps[8L * blockIdx.x + 0] = __builtin_amdgcn_s_memtime(); epi.stamps[8L * blockIdx.x + 4] = __builtin_amdgcn_s_getreg(6164); epi.stamps[8L * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime(); }
     if (r_begin < r_end) {
         fetch(r_begin);
         stash();
         __syncthreads();
-        if (epi.stamps && tid == 0) epi.stamps[4L * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+        if (epi.stamps && tid == 0) epi.stamps[8L * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
         for (int r0 = r_begin; r0 < r_end; r0 += BK) {
             const bool more = r0 + BK < r_end;
             if (more) fetch(r0 + BK);
@@ -366,7 +422,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(ASrc A, BSrc B, Epilogue epi,
                 for (int r = 0; r < BK; ++r) csum += As[r * LDA + tid];
             }
 #pragma unroll
-            for (int kk = 0; kk < BK; kk += 8) {
+            for (int kk = kg * (BK / KW); kk < (kg + 1) * (BK / KW); kk += 8) {
                 f32x4 af[FM], bf[FN];
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
@@ -402,20 +458,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(ASrc A, BSrc B, Epilogue epi,
         }
     }
 
-    if (epi.stamps && tid == 0) epi.stamps[4L * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+    if (epi.stamps && tid == 0) epi.stamps[8L * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+    if (KW > 1) {
+        // sum the wave groups' accumulators (native C/D layout, lane-contiguous LDS patches, binary tree)
+        static_assert(KW == 1 || (KW / 2) * 4 * FM * FN * 16 * 64 <= LDS_FLOATS, "LDS too small for the k-group reduction");
+        constexpr int PATCH = FM * FN * 16 * 64;
+#pragma unroll
+        for (int half = KW / 2; half >= 1; half >>= 1) {
+            if (kg >= half && kg < 2 * half) {
+                float* dst = lds + ((kg - half) * 4 + wave) * PATCH + lane;
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) dst[((i * FN + j) * 16 + g) * 64] = acc[i][j][g];
+            }
+            __syncthreads();
+            if (kg < half) {
+                const float* src = lds + (kg * 4 + wave) * PATCH + lane;
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) acc[i][j][g] += src[((i * FN + j) * 16 + g) * 64];
+            }
+            __syncthreads();
+        }
+        if (kg != 0) return;
+    }
     Epilogue e = epi;
     e.C += (long)split * e.split_stride;
     run_epilogue<EPI, FM, FN>(e, acc, M, N, m0 + wm0, n0 + wn0, lane, lds + wave * EP_WAVE_FLOATS, e.vec_store != 0);
-    if (epi.stamps && tid == 0) epi.stamps[4L * blockIdx.x + 3] = __builtin_amdgcn_s_memtime();
+    if (epi.stamps && tid == 0) { epi.stamps[8L * blockIdx.x + 3] = __builtin_amdgcn_s_memtime(); epi.stamps[8L * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime(); }
     if (do_colsum && m0 + tid < M) epi.colsum[(long)split * epi.colsum_stride + m0 + tid] = csum;
 }
 
-template <int BM, int BN, int BK, bool A_RC, bool B_RC, int VEC, int EPI, bool SCALE_A, class ASrc, class BSrc>
+template <int BM, int BN, int BK, int KW, bool A_RC, bool B_RC, int VEC, int EPI, bool SCALE_A, class ASrc, class BSrc>
 void launch_cfg(const ASrc& A, const BSrc& B, const Epilogue& epi, int M, int N, int R, int splits, int r_per_split,
                 hipStream_t st) {
     int tm = cdiv(M, BM), tn = cdiv(N, BN);
     dim3 grid(tm * tn * splits);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, A_RC, B_RC, VEC, EPI, SCALE_A, ASrc, BSrc>), grid, dim3(256), 0, st, A, B, epi,
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, KW, A_RC, B_RC, VEC, EPI, SCALE_A, ASrc, BSrc>), grid, dim3(256 * KW), 0, st, A, B, epi,
                        M, N, R, r_per_split, tm, tn);
 }
 
@@ -439,12 +524,22 @@ void launch_gemm(const ASrc& A, const BSrc& B, const Epilogue& epi_in, int M, in
     auto waste = [&](int bn) { return (double)cdiv(N, bn) * bn / N; };
     static const int forced = getenv("CSWIN_GEMM_TILE") ? atoi(getenv("CSWIN_GEMM_TILE")) : 0;   // tuning aid
     static const long want = getenv("CSWIN_GEMM_WANT") ? atol(getenv("CSWIN_GEMM_WANT")) : 384;
-    (void)blocks; (void)waste; (void)want;
-    int pick = forced ? forced : 3;
-    if (pick == 1) launch_cfg<128, 128, 32, A_RC, B_RC, VEC, EPI, SCALE_A>(A, B, epi, M, N, R, splits, r_per_split, st);
-    else if (pick == 2) launch_cfg<128, 64, 32, A_RC, B_RC, VEC, EPI, SCALE_A>(A, B, epi, M, N, R, splits, r_per_split, st);
-    else if (pick == 3) launch_cfg<64, 64, 32, A_RC, B_RC, VEC, EPI, SCALE_A>(A, B, epi, M, N, R, splits, r_per_split, st);
-    else launch_cfg<64, 64, 64, A_RC, B_RC, VEC, EPI, SCALE_A>(A, B, epi, M, N, R, splits, r_per_split, st);
+    (void)waste; (void)want;
+    static const int forced_kw = getenv("CSWIN_GEMM_KW") ? atoi(getenv("CSWIN_GEMM_KW")) : 0;                    // tuning aid
+    if (forced == 1) return launch_cfg<128, 128, 32, 1, A_RC, B_RC, VEC, EPI, SCALE_A>(A, B, epi, M, N, R, splits, r_per_split, st);
+    if (forced == 2) return launch_cfg<128, 64, 32, 1, A_RC, B_RC, VEC, EPI, SCALE_A>(A, B, epi, M, N, R, splits, r_per_split, st);
+    // 64x64 tiles everywhere (measured best, profiles/round1_gemm_bench.txt).  With fewer than ~2 workgroups per CU and a long
+    // reduction, split the k-range of each tile over 2 or 4 wave groups so every SIMD still has independent MFMA chains.
+    const long nb = blocks(64, 64);
+    const int r_len = r_per_split < R ? r_per_split : R;
+    int kw = 1;
+    if (nb < 640 && r_len >= 256) kw = 2;
+    if (nb < 320 && r_len >= 512) kw = 4;
+    if (!A_RC && !B_RC && r_len >= 256 && kw < 2) kw = 2;      // weight gradients: measured 5-8 % faster
+    if (forced_kw) kw = forced_kw;
+    if (kw == 4) launch_cfg<64, 64, 64, 4, A_RC, B_RC, VEC, EPI, SCALE_A>(A, B, epi, M, N, R, splits, r_per_split, st);
+    else if (kw == 2) launch_cfg<64, 64, 64, 2, A_RC, B_RC, VEC, EPI, SCALE_A>(A, B, epi, M, N, R, splits, r_per_split, st);
+    else launch_cfg<64, 64, 32, 1, A_RC, B_RC, VEC, EPI, SCALE_A>(A, B, epi, M, N, R, splits, r_per_split, st);
 }
 
 long long* g_stamps = nullptr;     // debug only (cswin_debug_set_stamps)
@@ -632,6 +727,30 @@ int cswin_conv_tok_bwd_data(const float* dy, const float* w_permT, float* dx, in
     CSWIN_REQUIRE(dy && w_permT && dx, CSWIN_ERR_SHAPE, "conv_tok_bwd_data: null pointer");
     CSWIN_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0 && aligned16(dy) && aligned16(w_permT), CSWIN_ERR_ALIGN, "conv_tok_bwd_data: channels %% 4 and 16-B alignment required");
     int OH = (H + 2 * pad - ks) / stride + 1, OW = (W + 2 * pad - ks) / stride + 1;
+    if (ks == 3 && stride == 2 && pad == 1) {
+        // four parity classes, each a dense GEMM over only the taps that reach it (Merge_Block.conv, cswin_unet.py:208)
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                const int H2 = (H - py + 1) / 2, W2 = (W - px + 1) / 2;
+                if (H2 <= 0 || W2 <= 0) continue;
+                int kys = 0, kxs = 0, taps = 0, nt = 0;
+                for (int ky = (py ? 0 : 1); ky < 3; ky += 2)
+                    for (int kx = (px ? 0 : 1); kx < 3; kx += 2) {
+                        kys |= ky << (2 * nt);
+                        kxs |= kx << (2 * nt);
+                        taps |= (ky * 3 + kx) << (4 * nt);
+                        ++nt;
+                    }
+                const int Mc = B * H2 * W2, Rc = nt * Cout;
+                ConvTS2Src A = {dy, B, H, W, Cout, OH, OW, py, px, H2, W2, kys, kxs, Mc, Rc};
+                TapRowsSrc Bm = {w_permT, Cout, Cin, taps, Rc, Cin};
+                Epilogue e = plain_epilogue(dx, Cin);
+                e.rm_on = 1; e.rm_H = H; e.rm_W = W; e.rm_H2 = H2; e.rm_W2 = W2; e.rm_py = py; e.rm_px = px;
+                launch_gemm<true, false, 4, EPI_PLAIN, false>(A, Bm, e, Mc, Cin, Rc, 1, cdiv(Rc, BKMAX) * BKMAX, (hipStream_t)stream);
+            }
+        CSWIN_LAUNCH_CHECK();
+        return CSWIN_OK;
+    }
     int M = B * H * W, R = ks * ks * Cout;
     ConvTSrc A = {dy, B, H, W, Cout, OH, OW, ks, stride, pad, M, R};
     PlainSrc Bm = {w_permT, Cin, R, Cin, nullptr, 1};          // S(i = (tap, co), j = ci)

@@ -7,7 +7,7 @@ from cswin_unet_amd._lib import call, lib, ptr, stream
 M, N, K = (int(a) for a in sys.argv[1:4]); mode = sys.argv[4]
 x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda"); b = torch.randn(N, device="cuda")
 dy = torch.randn(M, N, device="cuda"); y = torch.empty(M, N, device="cuda"); dx = torch.empty(M, K, device="cuda")
-st = torch.zeros(65536, 4, dtype=torch.int64, device="cuda")
+st = torch.zeros(65536, 8, dtype=torch.int64, device="cuda")
 h = lib(); h.cswin_debug_set_stamps.argtypes = [ctypes.c_void_p]
 def run():
     if mode == "fwd": call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, stream())
@@ -26,3 +26,11 @@ for name, a, b_ in (("prologue", 0, 1), ("mainloop", 1, 2), ("epilogue", 2, 3), 
     print(f"  {name:9s} mean {d.mean():9.0f}  p10 {np.percentile(d,10):9.0f}  p90 {np.percentile(d,90):9.0f} cycles")
 st_rel = s[:, 0] - t0
 print("  start offsets: p50 %d p90 %d max %d ; end offsets: p10 %d p50 %d max %d" % (np.percentile(st_rel,50), np.percentile(st_rel,90), st_rel.max(), np.percentile(s[:,3]-t0,10), np.percentile(s[:,3]-t0,50), (s[:,3]-t0).max()))
+
+# wall-clock view (s_memrealtime, 100 MHz, common to all XCDs): when do workgroups start / end?
+r0, r1 = s[:, 5], s[:, 6]
+base = r0.min()
+print("  realtime (us): first start 0, last start %.2f, first end %.2f, last end %.2f" % ((r0.max()-base)/100, (r1.min()-base)/100, (r1.max()-base)/100))
+for x in sorted(set(s[:, 4] & 15)):
+    m = (s[:, 4] & 15) == x
+    print(f"   xcd {x}: {m.sum()} wgs, start {(r0[m].min()-base)/100:.2f}..{(r0[m].max()-base)/100:.2f}, end {(r1[m].min()-base)/100:.2f}..{(r1[m].max()-base)/100:.2f} us; mean life {(r1[m]-r0[m]).mean()/100:.2f} us")
