@@ -27,11 +27,12 @@ SIGNATURES = {
     "cswin_windows2img": (I, [P, P, I, I, I, I, I, I, P]),
     "cswin_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
     "cswin_layernorm_bwd_workspace": (SZ, [I, I]),
-    "cswin_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, P]),
+    "cswin_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, P, P]),
     "cswin_linear_fwd": (I, [P, P, I, P, P, P, P, P, P, I, I, I, I, P]),
     "cswin_linear_bwd_data": (I, [P, P, P, P, I, P, P, I, P, I, I, I, P]),
     "cswin_linear_bwd_weight_workspace": (SZ, [I, I, I]),
-    "cswin_linear_bwd_weight": (I, [P, P, P, I, P, I, P, P, P, SZ, I, I, I, P]),
+    "cswin_linear_bwd_weight": (I, [P, P, P, I, P, I, P, P, P, SZ, I, I, I, P, P]),
+    "cswin_rows_sum_multi": (I, [P, I, P]),
     "cswin_conv_tok_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "cswin_conv_tok_bwd_data": (I, [P, P, P, I, I, I, I, I, I, I, I, P]),
     "cswin_conv_tok_bwd_weight_workspace": (SZ, [I, I, I, I, I, I, I, I]),
@@ -50,6 +51,14 @@ SIGNATURES = {
     "cswin_sgd_flat": (I, [P, P, P, L, P, F, F, F, P]),
     "cswin_multi_copy": (I, [P, I, P]),
 }
+
+
+
+class ReduceJob(ctypes.Structure):
+    """Mirror of cswin_reduce_job (include/cswin_hip.h)."""
+    _fields_ = [("part", c_void_p), ("out", c_void_p), ("out2", c_void_p), ("n_first", ctypes.c_longlong),
+                ("n", ctypes.c_longlong), ("stride", ctypes.c_longlong), ("rows", c_int), ("reserved", c_int)]
+
 
 _lib = None
 

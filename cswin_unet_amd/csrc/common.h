@@ -94,3 +94,57 @@ static inline void launch_rows_sum(const float* part, float* out, float* out2, l
     else
         hipLaunchKernelGGL(rows_sum_kernel<8>, dim3(blocks), dim3(256), 0, st, part, out, out2, n_first, n, rows, stride);
 }
+
+// ---- deferred slab reductions: several producers' partial slabs reduced by ONE launch ----------------------------
+// (a CSWinBlock backward has six: four split-K weight gradients and two LayerNorm dgamma/dbeta; as separate launches
+// each costs ~5 us of pure launch latency)
+extern "C" {
+typedef struct cswin_reduce_job {
+    const float* part;       // [rows][stride] partial slabs
+    float* out;              // columns [0, n_first)
+    float* out2;             // columns [n_first, n) (may be NULL: then everything goes to out)
+    long long n_first, n, stride;
+    int rows, reserved;
+} cswin_reduce_job;
+}
+
+constexpr int CSWIN_MAX_REDUCE_JOBS = 8;
+struct ReduceJobs {
+    cswin_reduce_job j[CSWIN_MAX_REDUCE_JOBS];
+    int first_block[CSWIN_MAX_REDUCE_JOBS + 1];
+    int njobs;
+};
+
+static __global__ __launch_bounds__(512) void rows_sum_multi_kernel(ReduceJobs J) {
+    constexpr int G = 16;
+    __shared__ float red[G][33];
+    int k = 0;
+    while (k + 1 < J.njobs && (int)blockIdx.x >= J.first_block[k + 1]) ++k;
+    const cswin_reduce_job job = J.j[k];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const long i = (long)(blockIdx.x - J.first_block[k]) * 32 + c;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < job.n) {
+        int r = g;
+        for (; r + G < job.rows; r += 2 * G) {
+            s0 += job.part[(long)r * job.stride + i];
+            s1 += job.part[(long)(r + G) * job.stride + i];
+        }
+        if (r < job.rows) s0 += job.part[(long)r * job.stride + i];
+    }
+    red[g][c] = s0 + s1;
+    __syncthreads();
+    if (g == 0 && i < job.n) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < G; ++q) t += red[q][c];
+        if (job.out2 && i >= job.n_first) job.out2[i - job.n_first] = t;
+        else job.out[i] = t;
+    }
+}
+
+// run `job` now, or hand it to the caller (deferred != NULL) to be batched by cswin_rows_sum_multi
+static inline void reduce_now_or_defer(const cswin_reduce_job& job, cswin_reduce_job* deferred, hipStream_t st) {
+    if (deferred) *deferred = job;
+    else launch_rows_sum(job.part, job.out, job.out2, (long)job.n_first, (long)job.n, job.rows, (long)job.stride, st);
+}

@@ -664,7 +664,7 @@ size_t cswin_linear_bwd_weight_workspace(int M, int N, int K) {
 // dw[N,K] = (row_scale . dy)^T @ [x | x2];  dbias[N] = colsum(row_scale . dy)
 int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, int k_split, const float* row_scale,
                             int rows_per_sample, float* dw, float* dbias, void* workspace, size_t ws_bytes, int M,
-                            int N, int K, void* stream) {
+                            int N, int K, cswin_reduce_job* deferred, void* stream) {
     CSWIN_REQUIRE(dy && x && dw && M > 0 && N > 0 && K > 0, CSWIN_ERR_SHAPE, "linear_bwd_weight: bad arguments");
     CSWIN_REQUIRE(!x2 || (k_split > 0 && k_split < K), CSWIN_ERR_SHAPE, "linear_bwd_weight: bad concat split");
     CSWIN_REQUIRE(!row_scale || rows_per_sample > 0, CSWIN_ERR_SHAPE, "linear_bwd_weight: rows_per_sample must be > 0");
@@ -699,7 +699,8 @@ int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, in
     }
     CSWIN_LAUNCH_CHECK();
     long n = (long)N * K;
-    launch_rows_sum(slab, dw, dbias, n, n + (dbias ? N : 0), splits, slab_stride, st);
+    cswin_reduce_job job = {slab, dw, dbias, n, n + (dbias ? N : 0), slab_stride, splits, 0};
+    reduce_now_or_defer(job, deferred, st);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }
@@ -790,6 +791,24 @@ int cswin_conv_tok_bwd_weight(const float* dy, const float* x, float* dw_perm, f
     CSWIN_LAUNCH_CHECK();
     long n = (long)Cout * K;
     launch_rows_sum(slab, dw_perm, dbias, n, n + (dbias ? Cout : 0), splits, slab_stride, st);
+    CSWIN_LAUNCH_CHECK();
+    return CSWIN_OK;
+}
+
+// jobs: HOST array of njobs (<= 8) reductions left pending by *_bwd_weight / layernorm_bwd calls with `deferred` set
+int cswin_rows_sum_multi(const cswin_reduce_job* jobs, int njobs, void* stream) {
+    CSWIN_REQUIRE(jobs && njobs > 0 && njobs <= CSWIN_MAX_REDUCE_JOBS, CSWIN_ERR_SHAPE, "rows_sum_multi: 1..%d jobs", CSWIN_MAX_REDUCE_JOBS);
+    ReduceJobs J = {};
+    int blocks = 0;
+    for (int i = 0; i < njobs; ++i) {
+        CSWIN_REQUIRE(jobs[i].part && jobs[i].out && jobs[i].n > 0 && jobs[i].rows > 0, CSWIN_ERR_SHAPE, "rows_sum_multi: bad job %d", i);
+        J.j[i] = jobs[i];
+        J.first_block[i] = blocks;
+        blocks += (int)((jobs[i].n + 31) / 32);
+    }
+    J.first_block[njobs] = blocks;
+    J.njobs = njobs;
+    hipLaunchKernelGGL(rows_sum_multi_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, J);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }

@@ -172,7 +172,7 @@ size_t cswin_layernorm_bwd_workspace(int M, int C) {
 // dres may be NULL; dx may alias dres.  dgamma/dbeta are overwritten.
 int cswin_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         const float* dres, float* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes,
-                        int M, int C, void* stream) {
+                        int M, int C, cswin_reduce_job* deferred, void* stream) {
     CSWIN_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && M > 0, CSWIN_ERR_SHAPE, "layernorm_bwd: bad arguments");
     CSWIN_REQUIRE(ln_supported(C), CSWIN_ERR_UNSUPPORTED, "layernorm: C=%d not in {32,64,128,256,512,1024}", C);
     CSWIN_REQUIRE(workspace && ws_bytes >= cswin_layernorm_bwd_workspace(M, C), CSWIN_ERR_WORKSPACE, "layernorm_bwd: workspace too small");
@@ -189,7 +189,8 @@ int cswin_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
         case 1024: launch_bwd<64, 4>(dy, x, mean, rstd, gamma, dres, dx, partial, M, st); break;
     }
     CSWIN_LAUNCH_CHECK();
-    launch_rows_sum(partial, dgamma, dbeta, C, 2L * C, nblk, 2L * C, st);
+    cswin_reduce_job job = {partial, dgamma, dbeta, C, 2LL * C, 2LL * C, nblk, 0};
+    reduce_now_or_defer(job, deferred, st);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }

@@ -10,7 +10,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from ._lib import call, dev_f32, lib, ptr, stream
+from ._lib import ReduceJob, call, dev_f32, lib, ptr, stream
 
 __all__ = ["layer_norm", "linear", "mlp", "stripe_attention", "cswin_block", "conv_tokens", "patch_embed_conv", "carafe_reassemble",
            "tokens_to_nchw", "matmul_nn", "ce_dice_loss", "img2windows", "windows2img"]
@@ -106,7 +106,7 @@ class _LayerNorm(Function):
         nbytes = lib().cswin_layernorm_bwd_workspace(M, C)
         ws = _ws(nbytes, x.device)
         call("cswin_layernorm_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), None, ptr(dx), ptr(dg), ptr(db),
-             ptr(ws), nbytes, M, C, stream())
+             ptr(ws), nbytes, M, C, None, stream())
         return dx, dg, db, None
 
 
@@ -161,7 +161,7 @@ class _Linear(Function):
                 nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
                 ws = _ws(nbytes, w.device)
                 call("cswin_linear_bwd_weight", ptr(dy), ptr(x), ptr(x2), K1 if x2 is not None else 0, ptr(row_scale), ctx.rps,
-                     ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, stream())
+                     ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, None, stream())
         dres = dy if ctx.has_res else None
         return dx, dw, db, dx2, dres, None
 
@@ -216,11 +216,10 @@ class _Mlp(Function):
             nbytes = max(lib().cswin_linear_bwd_weight_workspace(M, N, Hd), lib().cswin_linear_bwd_weight_workspace(M, Hd, K))
             ws = _ws(nbytes, dev)
             call("cswin_linear_bwd_weight", ptr(dy), ptr(act), None, 0, ptr(row_scale), ctx.rps, ptr(dw2), ptr(db2), ptr(ws),
-                 nbytes, M, N, Hd, stream())
+                 nbytes, M, N, Hd, None, stream())
             dw1 = torch.empty_like(w1)
             db1 = torch.empty(Hd, dtype=torch.float32, device=dev) if ctx.has_b1 else None
-            call("cswin_linear_bwd_weight", ptr(dpre), ptr(x), None, 0, None, 1, ptr(dw1), ptr(db1), ptr(ws), nbytes, M, Hd, K,
-                 stream())
+            call("cswin_linear_bwd_weight", ptr(dpre), ptr(x), None, 0, None, 1, ptr(dw1), ptr(db1), ptr(ws), nbytes, M, Hd, K, None, stream())
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None
 
 
@@ -253,7 +252,7 @@ class _MatmulNN(Function):
         db = torch.empty_like(b)        # db (N, K) = a^T @ dc
         nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
         ws = _ws(nbytes, a.device)
-        call("cswin_linear_bwd_weight", ptr(a), ptr(dc), None, 0, None, 1, ptr(db), None, ptr(ws), nbytes, M, N, K, stream())
+        call("cswin_linear_bwd_weight", ptr(a), ptr(dc), None, 0, None, 1, ptr(db), None, ptr(ws), nbytes, M, N, K, None, stream())
         return da, db
 
 
@@ -363,26 +362,35 @@ class _CSWinBlock(Function):
         M, Hd, nb = B * L, w1.shape[0], len(idx)
         dev, st, h = x.device, stream(), lib()
         E = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
-        nws = max(h.cswin_linear_bwd_weight_workspace(M, C, Hd), h.cswin_linear_bwd_weight_workspace(M, Hd, C),
-                  h.cswin_linear_bwd_weight_workspace(M, 3 * C, C), h.cswin_layernorm_bwd_workspace(M, C))
-        ws = _ws(nws, dev)
+        # six slab reductions (4 split-K weight gradients + 2 LayerNorm dgamma/dbeta) are deferred and run as ONE launch
+        sizes = [h.cswin_linear_bwd_weight_workspace(M, C, Hd), h.cswin_linear_bwd_weight_workspace(M, Hd, C),
+                 h.cswin_layernorm_bwd_workspace(M, C), h.cswin_linear_bwd_weight_workspace(M, C, C),
+                 h.cswin_linear_bwd_weight_workspace(M, 3 * C, C), h.cswin_layernorm_bwd_workspace(M, C)]
+        sizes = [(n + 255) // 256 * 256 for n in sizes]
+        ws = _ws(sum(sizes), dev)
+        wsp = [ctypes.c_void_p(ws.data_ptr() + sum(sizes[:i])) for i in range(6)]
+        jobs = (ReduceJob * 6)()
+        J = lambda i: ctypes.cast(ctypes.byref(jobs[i]), ctypes.c_void_p)
         # ---- MLP branch ----
         dpre = torch.empty_like(pre)
         call("cswin_linear_bwd_data", ptr(dy), ptr(w2), ptr(dpre), None, 0, ptr(pre), ptr(rs2), L, None, M, C, Hd, st)
         dw2, db2 = torch.empty_like(w2), E(C)
-        call("cswin_linear_bwd_weight", ptr(dy), ptr(act), None, 0, ptr(rs2), L, ptr(dw2), ptr(db2), ptr(ws), nws, M, C, Hd, st)
+        call("cswin_linear_bwd_weight", ptr(dy), ptr(act), None, 0, ptr(rs2), L, ptr(dw2), ptr(db2), wsp[0], sizes[0], M, C, Hd,
+             J(0), st)
         dw1, db1 = torch.empty_like(w1), E(Hd)
-        call("cswin_linear_bwd_weight", ptr(dpre), ptr(h2), None, 0, None, 1, ptr(dw1), ptr(db1), ptr(ws), nws, M, Hd, C, st)
+        call("cswin_linear_bwd_weight", ptr(dpre), ptr(h2), None, 0, None, 1, ptr(dw1), ptr(db1), wsp[1], sizes[1], M, Hd, C,
+             J(1), st)
         dh2 = torch.empty_like(x)
         call("cswin_linear_bwd_data", ptr(dpre), ptr(w1), ptr(dh2), None, 0, None, None, 1, None, M, Hd, C, st)
         dx1, dg2, dbt2 = torch.empty_like(x), E(C), E(C)
-        call("cswin_layernorm_bwd", ptr(dh2), ptr(x1), ptr(m2), ptr(r2), ptr(g2), ptr(dy), ptr(dx1), ptr(dg2), ptr(dbt2), ptr(ws),
-             nws, M, C, st)
+        call("cswin_layernorm_bwd", ptr(dh2), ptr(x1), ptr(m2), ptr(r2), ptr(g2), ptr(dy), ptr(dx1), ptr(dg2), ptr(dbt2), wsp[2],
+             sizes[2], M, C, J(2), st)
         # ---- attention branch ----
         datt = dh2                                                     # reuse
         call("cswin_linear_bwd_data", ptr(dx1), ptr(wp), ptr(datt), None, 0, None, ptr(rs1), L, None, M, C, C, st)
         dwp, dbp = torch.empty_like(wp), E(C)
-        call("cswin_linear_bwd_weight", ptr(dx1), ptr(att), None, 0, ptr(rs1), L, ptr(dwp), ptr(dbp), ptr(ws), nws, M, C, C, st)
+        call("cswin_linear_bwd_weight", ptr(dx1), ptr(att), None, 0, ptr(rs1), L, ptr(dwp), ptr(dbp), wsp[3], sizes[3], M, C, C,
+             J(3), st)
         dqkv = torch.empty_like(qkv)
         dlw = [torch.empty_like(t) for t in lw]
         dlb = [E(t.shape[0]) for t in lw]
@@ -393,12 +401,14 @@ class _CSWinBlock(Function):
              ptr(aws), naw, B, reso, C, nb, ha, ia, split, scale, st)
         dwqkv = torch.empty_like(wqkv)
         dbqkv = E(3 * C) if has_qkv_bias else None
-        call("cswin_linear_bwd_weight", ptr(dqkv), ptr(h1), None, 0, None, 1, ptr(dwqkv), ptr(dbqkv), ptr(ws), nws, M, 3 * C, C, st)
+        call("cswin_linear_bwd_weight", ptr(dqkv), ptr(h1), None, 0, None, 1, ptr(dwqkv), ptr(dbqkv), wsp[4], sizes[4], M, 3 * C, C,
+             J(4), st)
         dh1 = datt                                                     # reuse again
         call("cswin_linear_bwd_data", ptr(dqkv), ptr(wqkv), ptr(dh1), None, 0, None, None, 1, None, M, 3 * C, C, st)
         dx, dg1, dbt1 = torch.empty_like(x), E(C), E(C)
-        call("cswin_layernorm_bwd", ptr(dh1), ptr(x), ptr(m1), ptr(r1), ptr(g1), ptr(dx1), ptr(dx), ptr(dg1), ptr(dbt1), ptr(ws),
-             nws, M, C, st)
+        call("cswin_layernorm_bwd", ptr(dh1), ptr(x), ptr(m1), ptr(r1), ptr(g1), ptr(dx1), ptr(dx), ptr(dg1), ptr(dbt1), wsp[5],
+             sizes[5], M, C, J(5), st)
+        call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), 6, st)
         grads = (dx, None, None, None, None, None, None, None, None, None, dg1, dbt1, dwqkv, dbqkv, dwp, dbp, dg2, dbt2, dw1, db1,
                  dw2, db2)
         return grads + tuple(d.view(d.shape[0], 1, 3, 3) for d in dlw) + tuple(dlb)

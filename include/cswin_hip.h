@@ -33,6 +33,16 @@ extern "C" {
 #define CSWIN_ERR_HIP (-4)
 #define CSWIN_ERR_UNSUPPORTED (-5)
 
+/* A slab reduction left pending by a producer called with `deferred` != NULL; batch up to 8 of them into one launch with
+ * cswin_rows_sum_multi (a CSWinBlock backward has six: four weight gradients, two LayerNorm dgamma/dbeta). */
+typedef struct cswin_reduce_job {
+    const float* part;
+    float* out;
+    float* out2;
+    long long n_first, n, stride;
+    int rows, reserved;
+} cswin_reduce_job;
+
 const char* cswin_last_error(void);
 int cswin_abi_version(void);
 int cswin_device_ok(void); /* 1 if the current HIP device is gfx950 */
@@ -63,10 +73,11 @@ int cswin_windows2img(const float* win, float* out, int B, int C, int H, int W, 
 int cswin_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                         int M, int C, float eps, void* stream);
 size_t cswin_layernorm_bwd_workspace(int M, int C);
-/* dx = dres (optional residual-path gradient, may alias dx) + LN backward; dgamma/dbeta overwritten */
+/* dx = dres (optional residual-path gradient, may alias dx) + LN backward; dgamma/dbeta overwritten (by the returned
+ * job when `deferred` is given, immediately otherwise) */
 int cswin_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         const float* dres, float* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes,
-                        int M, int C, void* stream);
+                        int M, int C, cswin_reduce_job* deferred, void* stream);
 
 /* ---- nn.Linear family: qkv / proj / Mlp.fc1+GELU / fc2 (cswin_unet.py:125,134,17-27), concat_linear{4,3,2}
  *      (:404,417,428 with the torch.cat of :509,518,526 fused as a two-source K loop), 1x1 convs of CARAFE ----
@@ -82,10 +93,12 @@ int cswin_linear_bwd_data(const float* dy, const float* w, float* dx, float* dx2
                           const float* row_scale, int rows_per_sample, const float* add, int M, int N, int K,
                           void* stream);
 size_t cswin_linear_bwd_weight_workspace(int M, int N, int K);
-/* dw (N, K) = (row_scale * dy)^T @ [x | x2];  dbias (N) = column sums (may be NULL) */
+/* dw (N, K) = (row_scale * dy)^T @ [x | x2];  dbias (N) = column sums (may be NULL); `deferred` as for layernorm_bwd */
 int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, int k_split, const float* row_scale,
                             int rows_per_sample, float* dw, float* dbias, void* workspace, size_t ws_bytes, int M,
-                            int N, int K, void* stream);
+                            int N, int K, cswin_reduce_job* deferred, void* stream);
+/* jobs: host array of 1..8 pending reductions (the workspaces they point into must still be alive) */
+int cswin_rows_sum_multi(const cswin_reduce_job* jobs, int njobs, void* stream);
 
 /* ---- convolutions on tokens (NHWC) as implicit GEMM: stage1_conv_embed 7x7 s4 p2 (cswin_unet.py:339),
  *      Merge_Block 3x3 s2 p1 (:208,214-217), CARAFE encoder 3x3 s1 p1 (:228-229,241) ----

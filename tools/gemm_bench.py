@@ -35,7 +35,7 @@ for name, M, N, K in shapes:
     ws = torch.empty(nbytes // 4 + 4, device="cuda")
     tf = timed(lambda: call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, stream()))
     tdx = timed(lambda: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, stream()))
-    tdw = timed(lambda: call("cswin_linear_bwd_weight", ptr(dy), ptr(x), None, 0, None, 1, ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, stream()))
+    tdw = timed(lambda: call("cswin_linear_bwd_weight", ptr(dy), ptr(x), None, 0, None, 1, ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, None, stream()))
     fl = 2.0 * M * N * K
     c = counts[name[:2]]
     tot["fwd"] += c * tf; tot["dx"] += c * tdx; tot["dw"] += c * tdw; flops += 3 * c * fl
