@@ -309,9 +309,10 @@ class CSWinTransformer(nn.Module):
 
     # decoder and skip connections: cat([skip, x], -1) -> Linear is one two-source GEMM
     def forward_up_features(self, x):
-        for blocks, up, cl, skip in ((self.stage_up4, self.upsample4, self.concat_linear4, self.x3),
-                                    (self.stage_up3, self.upsample3, self.concat_linear3, self.x2),
-                                    (self.stage_up2, self.upsample2, self.concat_linear2, self.x1)):
+        _, s1, s2, s3 = getattr(self, "dec_in", None) or (None, self.x1, self.x2, self.x3)
+        for blocks, up, cl, skip in ((self.stage_up4, self.upsample4, self.concat_linear4, s3),
+                                    (self.stage_up3, self.upsample3, self.concat_linear3, s2),
+                                    (self.stage_up2, self.upsample2, self.concat_linear2, s1)):
             x = up(self._run(blocks, x))
             x = ops.linear(skip, cl.weight, cl.bias, x2=x)
         x = self._run(self.stage_up1, x)
@@ -336,5 +337,14 @@ class CSWinTransformer(nn.Module):
 
     def forward(self, x):
         x = self.forward_features(x)
-        x = self.forward_up_features(x)
+        # Encoder/decoder boundary = the bottleneck and the three skips.  A trainer that back-propagates the two halves
+        # separately (to overlap the decoder's gradient all-reduce with the encoder's backward) sets
+        # `detach_decoder_inputs`: the decoder then consumes detached leaves (self.dec_in) and the trainer feeds their
+        # gradients into the encoder graph itself.  Off by default: loss.backward() reaches every parameter.
+        self.xb = x
+        bound = [x, self.x1, self.x2, self.x3]
+        if getattr(self, "detach_decoder_inputs", False) and torch.is_grad_enabled():
+            bound = [t.detach().requires_grad_() for t in bound]
+        self.dec_in = bound
+        x = self.forward_up_features(bound[0])
         return self.up_x4(x)

@@ -38,12 +38,8 @@ class FlatSGD:
                 p.data = view                       # parameters now alias the flat buffer
         self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
         self.lr = float(lr)
-        # gather table: one {src, dst, n} record per <= 16 Ki-float chunk.  dst/n are fixed; src follows p.grad.
-        # Host side is pinned and allocated here, so refreshing it inside a hipGraph capture allocates nothing.
-        nrows = sum((p.numel() + _CHUNK - 1) // _CHUNK for p in self.params)
-        self._table_host = torch.zeros(nrows, 3, dtype=torch.int64).pin_memory()
-        self._table = torch.zeros(nrows, 3, dtype=torch.int64, device=dev)
-        self._table_key = None
+        # gather tables: one {src, dst, n} record per <= 16 Ki-float chunk, per gathered parameter range
+        self._tables = {}
         self.param_groups = [{"lr": self.lr, "params": self.params}]   # torch.optim-like view for loops that poke lr
 
     # -- schedule -------------------------------------------------------------------------------------------
@@ -57,12 +53,19 @@ class FlatSGD:
             p.grad = None
 
     # -- step -----------------------------------------------------------------------------------------------
-    def _gather_table(self):
-        key = tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in self.params)
-        if key != self._table_key:
+    def flat_range(self, first, last):
+        """[lo, hi) element range of the flat buffers covered by parameters first..last-1."""
+        lo = self.offsets[first]
+        hi = self.offsets[last - 1] + (self.params[last - 1].numel() + 3) // 4 * 4
+        return lo, hi
+
+    def _gather_table(self, first, last):
+        key = tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in self.params[first:last])
+        slot = self._tables.setdefault((first, last), {"key": None})
+        if key != slot["key"]:
             rows = []
             base = self.flat_grad.data_ptr()
-            for p, o, src in zip(self.params, self.offsets, key):
+            for p, o, src in zip(self.params[first:last], self.offsets[first:last], key):
                 if src == 0:
                     raise RuntimeError("FlatSGD.step(): a parameter has no gradient")
                 if not p.grad.is_contiguous():
@@ -70,20 +73,24 @@ class FlatSGD:
                 n = p.numel()
                 for c in range(0, n, _CHUNK):
                     rows.append((src + 4 * c, base + 4 * (o + c), min(_CHUNK, n - c)))
-            capturing = torch.cuda.is_current_stream_capturing()
-            if not capturing:
+            if "host" not in slot:
+                # pinned host side allocated once per range (outside any capture: the first call is an eager warm-up)
+                slot["host"] = torch.zeros(len(rows), 3, dtype=torch.int64).pin_memory()
+                slot["dev"] = torch.zeros(len(rows), 3, dtype=torch.int64, device=self.flat_grad.device)
+            if not torch.cuda.is_current_stream_capturing():
                 torch.cuda.current_stream().synchronize()      # a previous async upload may still read the host buffer
-            self._table_host.numpy()[:] = np.asarray(rows, dtype=np.int64)
+            slot["host"].numpy()[:] = np.asarray(rows, dtype=np.int64)
             # async upload from pinned memory: a memcpy node when captured (the host buffer lives with the optimiser)
-            self._table.copy_(self._table_host, non_blocking=True)
-            self._table_key = key
-        return self._table
+            slot["dev"].copy_(slot["host"], non_blocking=True)
+            slot["key"] = key
+        return slot["dev"]
 
-    def gather_grads(self):
-        """Pack every p.grad into self.flat_grad (one launch)."""
+    def gather_grads(self, first=0, last=None):
+        """Pack p.grad of parameters first..last-1 into self.flat_grad (one launch)."""
         from .ops import join_wgrad_stream
         join_wgrad_stream()          # weight gradients may have been produced on the side stream
-        t = self._gather_table()
+        last = len(self.params) if last is None else last
+        t = self._gather_table(first, last)
         call("cswin_multi_copy", ptr(t), t.shape[0], stream())
         return self.flat_grad
 

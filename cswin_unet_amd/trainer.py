@@ -11,8 +11,9 @@ the execution model, MI355X-first:
     is the reference's, not a per-rank Dice.
   * gradients are packed by one multi-tensor launch into a flat buffer which is all-reduced in a few large buckets
     (sized for 7 point-to-point xGMI links, not for many small NVSwitch messages) and consumed by one fused SGD launch.
-  * the step is captured into two hipGraphs (forward + loss sums | loss backward + model backward + gradient packing)
-    with the two collectives between/after them, so ~1500 kernel launches cost two graph launches on the host.
+  * the step is captured into three hipGraphs (forward + loss sums | loss + decoder backward + packing | encoder backward
+    + packing) with the collectives between them, so ~1000 kernel launches cost three graph launches on the host and the
+    decoder half of the gradient all-reduce overlaps the encoder half of the backward pass.
 
 The protocol (which collectives, which scalings) lives in ``DataParallelTrainer`` and is device agnostic; the device work
 lives in an *engine*.  ``HipEngine`` is the product (C ABI kernels, hipGraphs).  tests/test_dp_gloo.py drives the same
@@ -60,12 +61,25 @@ def scale_lr_for_batch(base_lr, batch_size):
     return base_lr * batch_size / 24 if (batch_size != 24 and batch_size % 6 == 0) else base_lr
 
 
+DECODER_PREFIXES = ("stage_up", "upsample", "concat_linear", "norm_up", "output")
+
+
 class HipEngine:
-    """Device side of one training step on this rank's MI355X: C-ABI kernels, optionally replayed from two hipGraphs."""
+    """Device side of one training step on this rank's MI355X: C-ABI kernels, optionally replayed from hipGraphs.
+
+    Backward runs in two phases -- decoder half, then encoder half (the U-Net's boundary tensors are the bottleneck and
+    the three skips) -- each ending with the multi-tensor packing of its gradients, so that the data-parallel protocol
+    can put the decoder bucket on the wire (RCCL, own stream) while the encoder half is still computing."""
 
     def __init__(self, model, num_classes, lr, momentum, weight_decay, w_ce, w_dice, use_graph=True):
         self.model, self.ncls, self.w_ce, self.w_dice = model, num_classes, w_ce, w_dice
+        self.core = model.cswin_unet if hasattr(model, "cswin_unet") else model
+        names = [n for n, p in model.named_parameters() if p.requires_grad]
         self.opt = FlatSGD(model.parameters(), lr=lr, momentum=momentum, weight_decay=weight_decay)
+        is_dec = [any(seg.startswith(DECODER_PREFIXES) for seg in n.split(".")[:2]) for n in names]
+        self.n_enc = is_dec.index(True) if True in is_dec else len(names)
+        self.split_backward = 0 < self.n_enc < len(names) and all(is_dec[self.n_enc:]) and hasattr(self.core, "forward_features")
+        self.core.detach_decoder_inputs = self.split_backward
         dev = self.opt.flat_param.device
         self.sums = torch.zeros(1 + 3 * num_classes, dtype=torch.float32, device=dev)
         self.stats = torch.zeros(3, dtype=torch.float32, device=dev)          # [loss, ce, dice] of the last step
@@ -96,35 +110,71 @@ class HipEngine:
         call("cswin_loss_sums", ptr(logits.detach()), ptr(lab), ptr(self.sums), ptr(ws), nbytes, B, ncls, hw, stream())
         return logits
 
-    def _backward_pack(self, logits, lab, dice_grad_scale):
+    def _loss_grad(self, logits, lab, dice_grad_scale):
         B, ncls = logits.shape[:2]
         hw = logits.numel() // (B * ncls)
         dlogits = torch.empty_like(logits)
         call("cswin_loss_bwd", ptr(logits.detach()), ptr(lab), ptr(self._coef), None, ptr(dlogits),
              self.w_ce / float(B * hw), self.w_dice / ncls * dice_grad_scale, B, ncls, hw, stream())
+        return dlogits
+
+    def _backward_decoder(self, logits, lab, dice_grad_scale):
+        """loss backward + decoder half; returns the gradients of the boundary tensors."""
+        dlogits = self._loss_grad(logits, lab, dice_grad_scale)
+        params, n_enc = self.opt.params, self.n_enc
         self.opt.zero_grad()
-        logits.backward(dlogits)
-        self.opt.gather_grads()
+        if not self.split_backward:
+            logits.backward(dlogits)
+            self.opt.gather_grads()
+            return None
+        core = self.core
+        dec_in = list(core.dec_in)                    # detached leaves the decoder consumed (detach_decoder_inputs)
+        grads = torch.autograd.grad([logits], params[n_enc:] + dec_in, [dlogits])
+        for p, g in zip(params[n_enc:], grads):
+            p.grad = g
+        self.opt.gather_grads(n_enc, len(params))
+        return [core.xb, core.x1, core.x2, core.x3], list(grads[len(params) - n_enc:])
+
+    def _backward_encoder(self, boundary):
+        bound, dbound = boundary
+        params, n_enc = self.opt.params, self.n_enc
+        grads = torch.autograd.grad(bound, params[:n_enc], dbound)
+        for p, g in zip(params[:n_enc], grads):
+            p.grad = g
+        self.opt.gather_grads(0, n_enc)
+
+    def _phase_ranges(self):
+        n = len(self.opt.params)
+        if not self.split_backward:
+            return [self.opt.flat_range(0, n)]
+        return [self.opt.flat_range(self.n_enc, n), self.opt.flat_range(0, self.n_enc)]
 
     def _capture(self, img, lab, dice_grad_scale):
         # PyTorch's capture recipe: a few eager iterations on a side stream (allocator state and autograd's
-        # AccumulateGrad nodes then belong to a non-default stream), then capture both halves into one memory pool
+        # AccumulateGrad nodes then belong to a non-default stream), then capture all parts into one memory pool
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
                 logits = self._forward_sums(img, lab)
                 self.finalize(lab.numel())
-                self._backward_pack(logits, lab, dice_grad_scale)
+                boundary = self._backward_decoder(logits, lab, dice_grad_scale)
+                if boundary is not None:
+                    self._backward_encoder(boundary)
         torch.cuda.current_stream().wait_stream(side)
         self._img, self._lab = img.clone(), lab.clone()
         self.opt.zero_grad()
-        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
+        graphs = [torch.cuda.CUDAGraph()]
+        with torch.cuda.graph(graphs[0]):
             logits = self._forward_sums(self._img, self._lab)
-        with torch.cuda.graph(gb, pool=ga.pool()):
-            self._backward_pack(logits, self._lab, dice_grad_scale)
-        self._graphs = (ga, gb)
+        graphs.append(torch.cuda.CUDAGraph())
+        with torch.cuda.graph(graphs[1], pool=graphs[0].pool()):
+            boundary = self._backward_decoder(logits, self._lab, dice_grad_scale)
+        if boundary is not None:
+            graphs.append(torch.cuda.CUDAGraph())
+            with torch.cuda.graph(graphs[2], pool=graphs[0].pool()):
+                self._backward_encoder(boundary)
+        self._graphs = graphs
 
     # ---- protocol hooks -----------------------------------------------------------------------------------------
     def forward_sums(self, img, lab, dice_grad_scale):
@@ -145,12 +195,19 @@ class HipEngine:
         call("cswin_loss_finalize", ptr(self.sums), ptr(self.stats), ptr(self._coef), float(n_pixels_global), self.ncls,
              self.w_ce, self.w_dice, stream())
 
-    def backward_pack(self, dice_grad_scale):
-        """Loss backward + model backward + gradient packing -> self.flat_grad."""
+    def backward_phases(self, dice_grad_scale):
+        """Generator: runs one backward phase per iteration and yields the [lo, hi) range of flat_grad it completed."""
+        ranges = self._phase_ranges()
         if self._graphs is not None:
-            self._graphs[1].replay()
+            for g, r in zip(self._graphs[1:], ranges):
+                g.replay()
+                yield r
         else:
-            self._backward_pack(self._logits, self._lab_eager, dice_grad_scale)
+            boundary = self._backward_decoder(self._logits, self._lab_eager, dice_grad_scale)
+            yield ranges[0]
+            if boundary is not None:
+                self._backward_encoder(boundary)
+                yield ranges[1]
             self._logits = None
 
     def apply(self, grad_scale):
@@ -161,7 +218,7 @@ class DataParallelTrainer:
     """The data-parallel protocol of one step (device agnostic; see module docstring)."""
 
     def __init__(self, model=None, num_classes=9, base_lr=0.05, max_iterations=1000, momentum=0.9, weight_decay=1e-4,
-                 group=None, use_graph=True, buckets=4, w_ce=0.4, w_dice=0.6, engine=None):
+                 group=None, use_graph=True, buckets=2, w_ce=0.4, w_dice=0.6, engine=None, force_collectives=False):
         self.group = group
         self.world = dist.get_world_size(group) if group is not None else 1
         self.base_lr, self.max_iterations, self.iter_num = base_lr, max_iterations, 0
@@ -169,7 +226,9 @@ class DataParallelTrainer:
                                                                  w_ce, w_dice, use_graph)
         self.model = model
         self.nbuckets = max(1, buckets)
-        if self.world > 1:                      # identical replicas: rank 0's initial weights everywhere
+        # run the collectives even with one rank (they are identities then): lets a 1-GPU box exercise the RCCL path
+        self.collectives = self.world > 1 or (force_collectives and group is not None)
+        if self.collectives:                    # identical replicas: rank 0's initial weights everywhere
             dist.broadcast(self.engine.flat_param, src=0, group=group)
 
     @property
@@ -185,17 +244,20 @@ class DataParallelTrainer:
         # Dice is a function of GLOBAL sums; gradients are averaged over ranks afterwards, so the local Dice gradient
         # (already built from global coefficients) is pre-multiplied by world to survive the 1/world averaging.
         eng.forward_sums(img, lab, dice_grad_scale=float(world))
-        if world > 1:
+        if self.collectives:
             dist.all_reduce(eng.sums, group=self.group)                 # 1 + 3*ncls floats
         eng.finalize(lab.numel() * world)
-        eng.backward_pack(dice_grad_scale=float(world))
-        if world > 1:
-            g = eng.flat_grad
-            n = g.numel()
-            step = (n + self.nbuckets - 1) // self.nbuckets
-            works = [dist.all_reduce(g[o:min(o + step, n)], group=self.group, async_op=True) for o in range(0, n, step)]
-            for w in works:
-                w.wait()
+        works = []
+        for lo, hi in eng.backward_phases(dice_grad_scale=float(world)):
+            if self.collectives:
+                # this phase's gradients are final: put them on the wire now (RCCL runs on its own stream, ordered after
+                # the work enqueued so far) while the next backward phase computes.  Few large buckets: xGMI is 7
+                # point-to-point links, per-message latency matters more than on a switched fabric.
+                g = eng.flat_grad
+                step = max((hi - lo + self.nbuckets - 1) // self.nbuckets, 1)
+                works += [dist.all_reduce(g[o:min(o + step, hi)], group=self.group, async_op=True) for o in range(lo, hi, step)]
+        for w in works:
+            w.wait()
         eng.apply(grad_scale=1.0 / world)
         self.iter_num += 1
         eng.set_lr(poly_lr(self.base_lr, self.iter_num - 1, self.max_iterations))   # trainer.py:61-63

@@ -61,7 +61,13 @@ class OracleEngine:
         self.stats.copy_(torch.stack([self.w_ce * ce + self.w_dice * dice, ce, dice]))
         self.glob = glob.clone()
 
-    def backward_pack(self, dice_grad_scale):
+    def backward_phases(self, dice_grad_scale):
+        self._backward(dice_grad_scale)
+        half = self.flat_grad.numel() // 2          # two phases, to exercise the per-phase bucketed all-reduce
+        yield 0, half
+        yield half, self.flat_grad.numel()
+
+    def _backward(self, dice_grad_scale):
         # Dice evaluated at the GLOBAL sums, differentiated through this rank's contribution only
         s = self.local + (self.glob - self.local).detach()
         loss = self.w_ce * F.cross_entropy(self.logits, self.lab) + self.w_dice * dice_grad_scale * O.dice_from_sums(s)

@@ -382,3 +382,42 @@ def test_full_size_properties(N, ops):
     img = torch.randn(B, 64, 56, 56, generator=g).to(DEV)
     for hs, ws in ((56, 1), (1, 56), (7, 7)):
         assert torch.equal(N.windows2img(N.img2windows(img, hs, ws), hs, ws, 56, 56), img.permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_trainer_three_steps_vs_golden(N, golden, use_graph):
+    """The product training step (HipEngine: fused loss, two-phase backward, flat SGD, hipGraphs when use_graph) reproduces
+    the reference's 3-step SGD loss trajectory and weight checksum (golden g5; drop_path 0)."""
+    from cswin_unet_amd.trainer import DataParallelTrainer
+    g = golden("g5_model")
+    net = _golden_model(N)
+    net.train()
+    img = T(det_normal("model.x", (2, 1, 224, 224))).repeat(1, 3, 1, 1)
+    lab = T(det_labels("model.labels", (2, 224, 224), 9))
+    tr = DataParallelTrainer(net, 9, base_lr=0.05, max_iterations=100, use_graph=use_graph)
+    assert tr.engine.split_backward and 0 < tr.engine.n_enc < len(tr.engine.opt.params)
+    losses = [float(tr.train_step(img, lab)[0]) for _ in range(3)]
+    assert np.allclose(losses, g["sgd_losses"], rtol=2e-3), (losses, g["sgd_losses"])
+    chk = sum(float(p.detach().double().abs().sum()) for p in net.parameters())
+    assert abs(chk - float(g["sgd_weight_checksum"])) <= 1e-4 * float(g["sgd_weight_checksum"])
+
+
+def test_trainer_rccl_path_single_rank(N, golden):
+    """Same trajectory with the collectives actually issued (1-rank RCCL group: all-reduce is the identity): exercises the
+    broadcast, the 28-float loss all-reduce between the hipGraphs and the per-phase bucketed gradient all-reduces."""
+    import torch.distributed as dist
+    from cswin_unet_amd.trainer import DataParallelTrainer
+    g = golden("g5_model")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1)
+    try:
+        net = _golden_model(N)
+        net.train()
+        img = T(det_normal("model.x", (2, 1, 224, 224))).repeat(1, 3, 1, 1)
+        lab = T(det_labels("model.labels", (2, 224, 224), 9))
+        tr = DataParallelTrainer(net, 9, base_lr=0.05, max_iterations=100, group=dist.group.WORLD, force_collectives=True)
+        assert tr.collectives
+        losses = [float(tr.train_step(img, lab)[0]) for _ in range(3)]
+        assert np.allclose(losses, g["sgd_losses"], rtol=2e-3), (losses, g["sgd_losses"])
+    finally:
+        dist.destroy_process_group()
