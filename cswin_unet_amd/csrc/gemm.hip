@@ -500,7 +500,8 @@ void launch_cfg(const ASrc& A, const BSrc& B, const Epilogue& epi, int M, int N,
                 hipStream_t st) {
     int tm = cdiv(M, BM), tn = cdiv(N, BN);
     dim3 grid(tm * tn * splits);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, KW, A_RC, B_RC, VEC, EPI, SCALE_A, ASrc, BSrc>), grid, dim3(256 * KW), 0, st, A, B, epi,
+    static const int pad_lds = getenv("CSWIN_GEMM_PAD_LDS") ? atoi(getenv("CSWIN_GEMM_PAD_LDS")) : 0;   // tuning aid: caps residency
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, KW, A_RC, B_RC, VEC, EPI, SCALE_A, ASrc, BSrc>), grid, dim3(256 * KW), pad_lds, st, A, B, epi,
                        M, N, R, r_per_split, tm, tn);
 }
 
