@@ -40,6 +40,8 @@ struct AttnParams {
     float* y;              // (B, L, C)        forward output
     float* lse;            // (B, heads_total, L)
     const float* dy;       // (B, L, C)        backward input
+    const float* y_in;     // (B, L, C)        forward output (large-window backward only: delta = rowsum(dO o (y - lepe)))
+    float* delta;          // (B, heads_total, L) workspace (large-window backward only)
     float* dqkv;           // (B, L, 3C)       backward output
     int B, reso, C, heads_total;
     float scale;
@@ -430,6 +432,296 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
     }
 }
 
+// =====================================================================================
+// backward for windows larger than 112 tokens (384x384 inputs: N = 144, 288): two-pass, any N
+// =====================================================================================
+// The fused kernel above keeps Q, K, V, dO and the N x N dS of a window in LDS; beyond N = 112 that does not fit.  The
+// large-window path never holds more than 64 x 64 of anything:
+//   attn_delta_kernel   delta[q] = sum_d dO[q][d] (y[q][d] - lepe[q][d])      (= rowsum(P o dP), from the saved output)
+//   attn_bwd_kv_kernel  one workgroup per 64 keys: dK, dV complete in registers over all query chunks (+ LePE^T(dO))
+//   attn_bwd_q_kernel   one workgroup per 64 queries: dQ complete in registers over all key chunks (S, dP recomputed)
+//   lepe_wgrad_kernel   depthwise-conv weight/bias gradient partial slabs from global memory
+// 56 MFMAs per 16x16 tile pair instead of 40, no cross-workgroup reduction, deterministic.
+
+struct BigWg { int bi, b, win, g, blk, ih, iw, N; };
+
+__device__ __forceinline__ BigWg decode_big(const AttnParams& p, int wg, int nblk) {
+    BigWg w;
+    w.blk = wg % nblk;
+    const WgInfo i = decode_wg(p, wg / nblk);
+    w.bi = i.bi; w.b = i.b; w.win = i.win; w.g = i.g; w.ih = i.ih; w.iw = i.iw; w.N = i.N;
+    return w;
+}
+
+__device__ __forceinline__ int token_of2(const AttnBranch& br, int ih, int iw, int reso, int t) {
+    int r = t / br.W_sp, c = t - r * br.W_sp;
+    return (ih * br.H_sp + r) * reso + iw * br.W_sp + c;
+}
+
+// grid: ceil(B * L * heads_total / 32) blocks of 256 threads; 8 lanes per (token, head)
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
+    const int L = p.reso * p.reso, C3 = 3 * p.C;
+    const long item = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int j = threadIdx.x & 7;
+    const long total = (long)p.B * p.heads_total * L;
+    float part = 0.f;
+    long out_idx = -1;
+    if (item < total) {
+        const int l = (int)(item % L);
+        const int hg = (int)((item / L) % p.heads_total);
+        const int b = (int)(item / ((long)L * p.heads_total));
+        const int bi = (p.nbranch > 1 && hg >= p.br[1].head0) ? 1 : 0;
+        const AttnBranch& br = p.br[bi];
+        const int g = hg - br.head0;
+        const int ch0 = br.c0 + g * HD + 4 * j, cb = g * HD + 4 * j;
+        const int yy = l / p.reso, xx = l - yy * p.reso;
+        const int ih = yy / br.H_sp, r = yy - ih * br.H_sp, iw = xx / br.W_sp, c = xx - iw * br.W_sp;
+        f32x4 lepe = *reinterpret_cast<const f32x4*>(br.lepe_b + cb);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int r2 = r + ky - 1, c2 = c + kx - 1;
+                if ((unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp) {
+                    const int l2 = (ih * br.H_sp + r2) * p.reso + iw * br.W_sp + c2;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(p.qkv + ((long)b * L + l2) * C3 + 2 * p.C + ch0);
+                    const int tap = ky * 3 + kx;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) lepe[e] += br.lepe_w[(cb + e) * 9 + tap] * v[e];
+                }
+            }
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(p.y_in + ((long)b * L + l) * p.C + ch0);
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(p.dy + ((long)b * L + l) * p.C + ch0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part += dv[e] * (yv[e] - lepe[e]);
+        out_idx = item;     // delta layout (B, heads_total, L) == item order
+        out_idx = ((long)b * p.heads_total + hg) * L + l;
+    }
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    part += __shfl_xor(part, 4, 64);
+    if (j == 0 && out_idx >= 0) p.delta[out_idx] = part;
+}
+
+// one workgroup (4 waves) = 64 keys of one (branch, window, head); wave w owns keys [k0 + 16 w, +16)
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk) {
+    __shared__ __attribute__((aligned(16))) float Qc[64 * LDT];
+    __shared__ __attribute__((aligned(16))) float Dc[64 * LDT];
+    __shared__ __attribute__((aligned(16))) float lse_c[64];
+    __shared__ __attribute__((aligned(16))) float del_c[64];
+    const BigWg w = decode_big(p, blockIdx.x, nblk);
+    const AttnBranch& br = p.br[w.bi];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int L = p.reso * p.reso, C3 = 3 * p.C, N = w.N;
+    const int ch0 = br.c0 + w.g * HD;
+    const float* qkv_b = p.qkv + (long)w.b * L * C3;
+    const float* dy_b = p.dy + (long)w.b * L * p.C;
+    float* dqkv_b = p.dqkv + (long)w.b * L * C3;
+    const long stat_base = ((long)w.b * p.heads_total + br.head0 + w.g) * L;
+    const int tk = 64 * w.blk + 16 * wave + li;
+    const bool kvalid = tk < N;
+    const int lk = kvalid ? token_of2(br, w.ih, w.iw, p.reso, tk) : 0;
+    float kf[8], vf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) kf[e] = vf[e] = 0.f;
+    if (kvalid) {
+        const float* src = qkv_b + (long)lk * C3 + ch0 + 8 * kq;
+        const f32x4 k0 = *reinterpret_cast<const f32x4*>(src + p.C), k1 = *reinterpret_cast<const f32x4*>(src + p.C + 4);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 2 * p.C), v1 = *reinterpret_cast<const f32x4*>(src + 2 * p.C + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { kf[e] = k0[e]; kf[4 + e] = k1[e]; vf[e] = v0[e]; vf[4 + e] = v1[e]; }
+    }
+    f32x4 dVt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 dKt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int q0 = 0; q0 < N; q0 += 64) {
+        for (int idx = tid; idx < 64 * 8; idx += 256) {
+            const int row = idx >> 3, c4 = idx & 7, tq = q0 + row;
+            f32x4 qv = {0.f, 0.f, 0.f, 0.f}, dv = qv;
+            if (tq < N) {
+                const int l = token_of2(br, w.ih, w.iw, p.reso, tq);
+                qv = *reinterpret_cast<const f32x4*>(qkv_b + (long)l * C3 + ch0 + 4 * c4);
+                dv = *reinterpret_cast<const f32x4*>(dy_b + (long)l * p.C + ch0 + 4 * c4);
+            }
+            *reinterpret_cast<f32x4*>(&Qc[row * LDT + 4 * c4]) = qv;
+            *reinterpret_cast<f32x4*>(&Dc[row * LDT + 4 * c4]) = dv;
+        }
+        if (tid < 128) {
+            const int row = tid & 63, tq = q0 + row;
+            const bool ok = tq < N;
+            const int l = ok ? token_of2(br, w.ih, w.iw, p.reso, tq) : 0;
+            if (tid < 64) lse_c[row] = ok ? p.lse[stat_base + l] : INFINITY;
+            else del_c[row] = ok ? p.delta[stat_base + l] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            const float* qp = &Qc[(16 * qt + li) * LDT + 8 * kq];
+            const float* dp = &Dc[(16 * qt + li) * LDT + 8 * kq];
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, da = sa;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sa = mfma4(qp[e], kf[e], sa);
+                da = mfma4(dp[e], vf[e], da);
+            }
+            const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_c[16 * qt + 4 * kq]);
+            const f32x4 de = *reinterpret_cast<const f32x4*>(&del_c[16 * qt + 4 * kq]);
+            f32x4 pv, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pv[r] = kvalid ? __expf(sa[r] * p.scale - ls[r]) : 0.f;
+                ds[r] = pv[r] * (da[r] - de[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qrow = 16 * qt + 4 * kq + r;
+                const float* dop = &Dc[qrow * LDT + li];
+                const float* qq = &Qc[qrow * LDT + li];
+                dVt[0] = mfma4(dop[0], pv[r], dVt[0]);
+                dVt[1] = mfma4(dop[16], pv[r], dVt[1]);
+                dKt[0] = mfma4(qq[0], ds[r], dKt[0]);
+                dKt[1] = mfma4(qq[16], ds[r], dKt[1]);
+            }
+        }
+        __syncthreads();
+    }
+    if (kvalid) {
+        const int rr = tk / br.W_sp, cc = tk - rr * br.W_sp;
+#pragma unroll
+        for (int df = 0; df < 2; ++df) {
+            const int d0 = 16 * df + 4 * kq, cb = w.g * HD + d0;
+            f32x4 acc = dVt[df];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int r2 = rr - ky + 1, c2 = cc - kx + 1;
+                    if ((unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp) {
+                        const int l2 = token_of2(br, w.ih, w.iw, p.reso, r2 * br.W_sp + c2);
+                        const f32x4 dv = *reinterpret_cast<const f32x4*>(dy_b + (long)l2 * p.C + ch0 + d0);
+                        const int tap = ky * 3 + kx;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[e] += br.lepe_w[(cb + e) * 9 + tap] * dv[e];
+                    }
+                }
+            float* dst = dqkv_b + (long)lk * C3 + ch0 + d0;
+            *reinterpret_cast<f32x4*>(dst + p.C) = dKt[df] * p.scale;
+            *reinterpret_cast<f32x4*>(dst + 2 * p.C) = acc;
+        }
+    }
+}
+
+// one workgroup (4 waves) = 64 queries of one (branch, window, head); wave w owns queries [q0 + 16 w, +16)
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk) {
+    __shared__ __attribute__((aligned(16))) float Kc[64 * LDT];
+    __shared__ __attribute__((aligned(16))) float Vc[64 * LDT];
+    const BigWg w = decode_big(p, blockIdx.x, nblk);
+    const AttnBranch& br = p.br[w.bi];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int L = p.reso * p.reso, C3 = 3 * p.C, N = w.N;
+    const int ch0 = br.c0 + w.g * HD;
+    const float* qkv_b = p.qkv + (long)w.b * L * C3;
+    const float* dy_b = p.dy + (long)w.b * L * p.C;
+    float* dqkv_b = p.dqkv + (long)w.b * L * C3;
+    const long stat_base = ((long)w.b * p.heads_total + br.head0 + w.g) * L;
+    const int tq = 64 * w.blk + 16 * wave + li;
+    const bool qvalid = tq < N;
+    const int lq = qvalid ? token_of2(br, w.ih, w.iw, p.reso, tq) : 0;
+    float qr[8], dor[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qr[e] = dor[e] = 0.f;
+    float lse_q = INFINITY, del_q = 0.f;
+    if (qvalid) {
+        const float* src = qkv_b + (long)lq * C3 + ch0 + 8 * kq;
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(src), q1 = *reinterpret_cast<const f32x4*>(src + 4);
+        const float* dsrc = dy_b + (long)lq * p.C + ch0 + 8 * kq;
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(dsrc), d1 = *reinterpret_cast<const f32x4*>(dsrc + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { qr[e] = q0[e] * p.scale; qr[4 + e] = q1[e] * p.scale; dor[e] = d0[e]; dor[4 + e] = d1[e]; }
+        lse_q = p.lse[stat_base + lq];
+        del_q = p.delta[stat_base + lq];
+    }
+    f32x4 dQt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int k0 = 0; k0 < N; k0 += 64) {
+        for (int idx = tid; idx < 64 * 8; idx += 256) {
+            const int row = idx >> 3, c4 = idx & 7, tk = k0 + row;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+            if (tk < N) {
+                const float* src = qkv_b + (long)token_of2(br, w.ih, w.iw, p.reso, tk) * C3 + ch0 + 4 * c4;
+                kv = *reinterpret_cast<const f32x4*>(src + p.C);
+                vv = *reinterpret_cast<const f32x4*>(src + 2 * p.C);
+            }
+            *reinterpret_cast<f32x4*>(&Kc[row * LDT + 4 * c4]) = kv;
+            *reinterpret_cast<f32x4*>(&Vc[row * LDT + 4 * c4]) = vv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const float* kp = &Kc[(16 * kt + li) * LDT + 8 * kq];
+            const float* vp = &Vc[(16 * kt + li) * LDT + 8 * kq];
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, da = sa;       // S^T / dP^T tiles: rows = keys, col = this lane's query
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sa = mfma4(kp[e], qr[e], sa);
+                da = mfma4(vp[e], dor[e], da);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool kok = k0 + 16 * kt + 4 * kq + r < N;
+                const float pv = kok ? __expf(sa[r] - lse_q) : 0.f;
+                const float ds = pv * (da[r] - del_q);
+                const float* kk = &Kc[(16 * kt + 4 * kq + r) * LDT + li];
+                dQt[0] = mfma4(kk[0], ds, dQt[0]);
+                dQt[1] = mfma4(kk[16], ds, dQt[1]);
+            }
+        }
+        __syncthreads();
+    }
+    if (qvalid) {
+        float* dst = dqkv_b + (long)lq * C3 + ch0 + 4 * kq;
+        *reinterpret_cast<f32x4*>(dst) = dQt[0] * p.scale;
+        *reinterpret_cast<f32x4*>(dst + 16) = dQt[1] * p.scale;
+    }
+}
+
+// LePE conv weight/bias gradient partial slabs from global memory; one workgroup per (branch, window, head)
+__global__ __launch_bounds__(256) void lepe_wgrad_kernel(AttnParams p) {
+    __shared__ float scratch[8 * 10 * HD];
+    const WgInfo w = decode_wg(p, blockIdx.x);
+    const AttnBranch& br = p.br[w.bi];
+    const int tid = threadIdx.x, d = tid & 31, tg = tid >> 5;
+    const int L = p.reso * p.reso, C3 = 3 * p.C, N = w.N;
+    const int ch0 = br.c0 + w.g * HD;
+    const float* v_b = p.qkv + (long)w.b * L * C3 + 2 * p.C + ch0 + d;
+    const float* dy_b = p.dy + (long)w.b * L * p.C + ch0 + d;
+    float a[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) a[i] = 0.f;
+    for (int t = tg; t < N; t += 8) {
+        const int rr = t / br.W_sp, cc = t - rr * br.W_sp;
+        const float g = dy_b[(long)token_of(br, w, p.reso, t) * p.C];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int r2 = rr + ky - 1, c2 = cc + kx - 1;
+                if ((unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp)
+                    a[ky * 3 + kx] += g * v_b[(long)token_of(br, w, p.reso, r2 * br.W_sp + c2) * C3];
+            }
+        a[9] += g;
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) scratch[(tg * 10 + i) * HD + d] = a[i];
+    __syncthreads();
+    for (int i = tid; i < 10 * HD; i += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += scratch[k * 10 * HD + i];
+        br.dw_part[(long)(blockIdx.x - br.wg_begin) * 10 * HD + i] = s;
+    }
+}
+
 // dw[cb][tap] / db[cb] = sum over (b, window) of the partial slabs.  One workgroup per (head, tap-or-bias).
 __global__ __launch_bounds__(1024) void lepe_grad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                  float* __restrict__ db, int heads, int nslab) {
@@ -600,32 +892,48 @@ size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* 
     AttnParams p = {};
     int nt, nwg;
     if (fill_params(p, "attn_bwd_workspace", B, reso, C, nbranch, heads, idx, split, 0.f, &nt, &nwg)) return 0;
-    return (size_t)nwg * 10 * HD * sizeof(float);
+    // LePE partial slabs + (windows > 112 tokens only) delta (B, heads, L)
+    size_t n = (size_t)nwg * 10 * HD;
+    if (nt > 7) n += (size_t)B * p.heads_total * reso * reso;
+    return n * sizeof(float);
 }
 
 // dqkv (B, L, 3C) is fully overwritten; dlepe_w[i] (Cb,9) and dlepe_b[i] (Cb) are overwritten.
-int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* lse, const float* dy, float* dqkv,
-                   float* const* dlepe_w, float* const* dlepe_b, void* workspace, size_t ws_bytes, int B, int reso,
-                   int C, int nbranch, const int* heads, const int* idx, int split, float scale, void* stream) {
+int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, const float* lse,
+                   const float* y, const float* dy, float* dqkv, float* const* dlepe_w, float* const* dlepe_b,
+                   void* workspace, size_t ws_bytes, int B, int reso, int C, int nbranch, const int* heads, const int* idx,
+                   int split, float scale, void* stream) {
     AttnParams p = {};
     int nt, nwg;
     int rc = fill_params(p, "attn_bwd", B, reso, C, nbranch, heads, idx, split, scale, &nt, &nwg);
     if (rc) return rc;
     CSWIN_REQUIRE(qkv && lse && dy && dqkv && lepe_w && dlepe_w && dlepe_b, CSWIN_ERR_SHAPE, "attn_bwd: null pointer");
-    CSWIN_REQUIRE(workspace && ws_bytes >= (size_t)nwg * 10 * HD * sizeof(float), CSWIN_ERR_WORKSPACE, "attn_bwd: workspace too small");
+    CSWIN_REQUIRE(workspace && ws_bytes >= cswin_attn_bwd_workspace(B, reso, C, nbranch, heads, idx, split), CSWIN_ERR_WORKSPACE, "attn_bwd: workspace too small");
     for (int i = 0; i < nbranch; ++i) {
         p.br[i].lepe_w = lepe_w[i];
+        p.br[i].lepe_b = lepe_b ? lepe_b[i] : nullptr;
         p.br[i].dw_part = (float*)workspace + (size_t)p.br[i].wg_begin * 10 * HD;
     }
+    p.y_in = y;
+    p.delta = (float*)workspace + (size_t)nwg * 10 * HD;
     p.qkv = qkv; p.lse = const_cast<float*>(lse); p.dy = dy; p.dqkv = dqkv;
     hipStream_t st = (hipStream_t)stream;
-    switch (nt) {
-        case 1: case 2: case 3: case 4: rc = launch_bwd<4>(p, nwg, st); break;
-        case 5: case 6: rc = launch_bwd<6>(p, nwg, st); break;
-        case 7: rc = launch_bwd<7>(p, nwg, st); break;
-        default:
-            cswin_set_error("attn_bwd: window of %d tokens unsupported (backward handles <= 112)", p.br[0].H_sp * p.br[0].W_sp);
-            return CSWIN_ERR_UNSUPPORTED;
+    if (nt > 7) {
+        // windows of more than 112 tokens (384x384: N = 144, 288): two-pass path, needs the forward output and the LePE bias
+        CSWIN_REQUIRE(y && lepe_b, CSWIN_ERR_SHAPE, "attn_bwd: windows of %d tokens need y and lepe_b (large-window path)", p.br[0].H_sp * p.br[0].W_sp);
+        const int N = p.br[0].H_sp * p.br[0].W_sp, nblk = (N + 63) / 64;
+        const long items = (long)B * p.heads_total * reso * reso;
+        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items * 8 + 255) / 256)), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(nwg * nblk), dim3(256), 0, st, p, nblk);
+        hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(nwg * nblk), dim3(256), 0, st, p, nblk);
+        hipLaunchKernelGGL(lepe_wgrad_kernel, dim3(nwg), dim3(256), 0, st, p);
+        rc = CSWIN_OK;
+    } else {
+        switch (nt) {
+            case 1: case 2: case 3: case 4: rc = launch_bwd<4>(p, nwg, st); break;
+            case 5: case 6: rc = launch_bwd<6>(p, nwg, st); break;
+            default: rc = launch_bwd<7>(p, nwg, st); break;
+        }
     }
     if (rc) return rc;
     CSWIN_LAUNCH_CHECK();

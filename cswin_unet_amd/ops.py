@@ -278,17 +278,18 @@ class _StripeAttention(Function):
         lse = torch.empty(B, sum(heads), L, dtype=torch.float32, device=qkv.device)
         call("cswin_attn_fwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(y), ptr(lse), B, reso, C, nb,
              _int_array(heads), _int_array(idx), split, float(scale or 0.0), stream())
-        ctx.save_for_backward(qkv, lse, *ws_)
+        ctx.save_for_backward(qkv, lse, y, *ws_, *bs_)
         ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0))
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        qkv, lse, *ws_ = ctx.saved_tensors
+        qkv, lse, y, *wb_ = ctx.saved_tensors
         reso, split, idx, heads, scale = ctx.meta
         dy = dev_f32(dy)
         nb = len(idx)
+        ws_, bs_ = wb_[:nb], wb_[nb:]
         B, L, C3 = qkv.shape
         C = C3 // 3
         dqkv = torch.empty_like(qkv)
@@ -297,8 +298,8 @@ class _StripeAttention(Function):
         ha, ia = _int_array(heads), _int_array(idx)
         nbytes = lib().cswin_attn_bwd_workspace(B, reso, C, nb, ha, ia, split)
         ws = _ws(nbytes, qkv.device)
-        call("cswin_attn_bwd", ptr(qkv), _ptr_array(ws_), ptr(lse), ptr(dy), ptr(dqkv), _ptr_array(dws), _ptr_array(dbs),
-             ptr(ws), nbytes, B, reso, C, nb, ha, ia, split, scale, stream())
+        call("cswin_attn_bwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(lse), ptr(y), ptr(dy), ptr(dqkv), _ptr_array(dws),
+             _ptr_array(dbs), ptr(ws), nbytes, B, reso, C, nb, ha, ia, split, scale, stream())
         return (dqkv, None, None, None, None, None) + tuple(d.view(d.shape[0], 1, 3, 3) for d in dws) + tuple(dbs)
 
 
@@ -348,15 +349,16 @@ class _CSWinBlock(Function):
         call("cswin_linear_fwd", ptr(h2), None, 0, ptr(w1), ptr(bb1), ptr(pre), ptr(act), None, None, 1, M, Hd, C, st)
         y = torch.empty_like(x)
         call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(bb2), ptr(y), None, ptr(x1), ptr(rs2), L, M, C, Hd, st)
-        ctx.save_for_backward(x, m1, r1, h1, qkv, lse, att, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lw)
+        ctx.save_for_backward(x, m1, r1, h1, qkv, lse, att, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lw, *lb)
         ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0), bqkv is not None)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        (x, m1, r1, h1, qkv, lse, att, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lw) = ctx.saved_tensors
+        (x, m1, r1, h1, qkv, lse, att, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lwb) = ctx.saved_tensors
         reso, split, idx, heads, scale, has_qkv_bias = ctx.meta
+        lw, lb = lwb[:len(idx)], lwb[len(idx):]
         dy = dev_f32(dy)
         B, L, C = x.shape
         M, Hd, nb = B * L, w1.shape[0], len(idx)
@@ -397,8 +399,8 @@ class _CSWinBlock(Function):
         ha, ia = _int_array(heads), _int_array(idx)
         naw = h.cswin_attn_bwd_workspace(B, reso, C, nb, ha, ia, split)
         aws = _ws(naw, dev)
-        call("cswin_attn_bwd", ptr(qkv), _ptr_array(lw), ptr(lse), ptr(datt), ptr(dqkv), _ptr_array(dlw), _ptr_array(dlb),
-             ptr(aws), naw, B, reso, C, nb, ha, ia, split, scale, st)
+        call("cswin_attn_bwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(lse), ptr(att), ptr(datt), ptr(dqkv),
+             _ptr_array(dlw), _ptr_array(dlb), ptr(aws), naw, B, reso, C, nb, ha, ia, split, scale, st)
         dwqkv = torch.empty_like(wqkv)
         dbqkv = E(3 * C) if has_qkv_bias else None
         call("cswin_linear_bwd_weight", ptr(dqkv), ptr(h1), None, 0, None, 1, ptr(dwqkv), ptr(dbqkv), wsp[4], sizes[4], M, 3 * C, C,

@@ -176,15 +176,22 @@ def test_attention_vs_golden(N, golden, reso, idx, split, dim, heads):
 
 
 @pytest.mark.parametrize("reso,idx,split,dim,heads", ATTN384)
-def test_attention_384_forward_vs_golden(N, golden, reso, idx, split, dim, heads):
+def test_attention_384_fwd_bwd_vs_golden(N, golden, reso, idx, split, dim, heads):
+    """384x384 stripe shapes (N = 96, 288, 144): forward with online tiles over up to 18 key tiles, backward through the
+    large-window two-pass path (delta pre-pass, dK/dV pass, dQ pass, LePE gradient pass) for N > 112."""
     g = golden("g2_attention")
     key = f"r{reso}_i{idx}_s{split}"
     L = reso * reso
     att = N.LePEAttention(dim, resolution=reso, idx=idx, split_size=split, num_heads=heads).to(DEV)
     fill_state_dict(att, prefix=f"attn.{key}.")
-    with torch.no_grad():
-        y = att([T(det_normal(f"attn.{key}.{n}", (2, L, dim))) for n in "qkv"])
-    check_packed(y, g, f"{key}.y.", RTOL, what="attention384 ")
+    q, k, v = (T(det_normal(f"attn.{key}.{n}", (2, L, dim)), True) for n in "qkv")
+    y = att([q, k, v])
+    y.backward(T(det_normal(f"attn.{key}.dy", (2, L, dim))))
+    for name, t in [("y", y), ("dq", q.grad), ("dk", k.grad), ("dv", v.grad), ("dw", att.get_v.weight.grad),
+                    ("db", att.get_v.bias.grad)]:
+        err = check_packed(t, g, f"{key}.{name}.", RTOL, what="attention384 ")
+        with open(LOG, "a") as f:
+            f.write(f"attn384_golden.{key}.{name}: {err:.3e}\n")
 
 
 @pytest.mark.parametrize("dim,reso,heads,split,last", [(64, 56, 2, 1, False), (128, 28, 4, 2, False),
@@ -421,3 +428,26 @@ def test_trainer_rccl_path_single_rank(N, golden):
         assert np.allclose(losses, g["sgd_losses"], rtol=2e-3), (losses, g["sgd_losses"])
     finally:
         dist.destroy_process_group()
+
+
+def test_model_384_training_step_vs_oracle(N, ops, golden):
+    """BASELINE configs[3] shape (384x384, split [1,2,12,12]) end to end at B=1: logits vs the reference golden, loss and a
+    sample of parameter gradients vs the CPU oracle (backward goes through the large-window attention path)."""
+    cfg = dict(O.TINY_224, img_size=384, split_size=(1, 2, 12, 12))
+    net = N.CSWinTransformer(img_size=384, num_classes=9, embed_dim=64, depth=[1, 2, 9, 1], split_size=[1, 2, 12, 12],
+                             num_heads=[2, 4, 8, 16], qkv_bias=True).to(DEV)
+    fill_state_dict(net).train()
+    img = det_normal("model384.x", (1, 3, 384, 384))
+    lab = det_labels("model384.lab", (1, 384, 384), 9)
+    logits = net(T(img))
+    check_packed(logits, golden("g7_model384"), "logits.", RTOL, what="model384 ")
+    loss, _ = ops.ce_dice_loss(logits, T(lab))
+    loss.backward()
+    P = O.golden_params(cfg)
+    ref_loss, _, _ = O.ce_dice_loss(O.cswin_forward(P, torch.from_numpy(img), cfg), torch.from_numpy(lab))
+    ref_loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < 1e-3 * abs(float(ref_loss))
+    params = dict(net.named_parameters())
+    for n in ["stage3.4.qkv.weight", "stage3.4.attns.1.get_v.weight", "stage4.0.attns.0.get_v.bias", "stage_up3.2.proj.weight",
+              "stage1_conv_embed.0.weight", "merge2.conv.weight", "upsample1.encoder.weight", "output.weight"]:
+        rel_err(params[n].grad, P[n].grad, "model384.grad." + n)

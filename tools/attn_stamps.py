@@ -18,7 +18,7 @@ ia, ha = (ctypes.c_int * nb)(*idx), (ctypes.c_int * nb)(*hb)
 pa = lambda ts: (ctypes.c_void_p * nb)(*[t.data_ptr() for t in ts])
 nbytes = lib().cswin_attn_bwd_workspace(batch, reso, C, nb, ha, ia, split[si]); ws = torch.empty(nbytes // 4 + 4, device=dev)
 call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(lse), batch, reso, C, nb, ha, ia, split[si], 0.0, stream())
-def bwd(): call("cswin_attn_bwd", ptr(qkv), pa(w), ptr(lse), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws), nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, stream())
+def bwd(): call("cswin_attn_bwd", ptr(qkv), pa(w), pa(b), ptr(lse), ptr(y), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws), nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, stream())
 for _ in range(3): bwd()
 torch.cuda.synchronize()
 st = torch.zeros(1 << 16, 8, dtype=torch.int64, device=dev)
