@@ -44,6 +44,7 @@ struct AttnParams {
     float* delta;          // (B, heads_total, L) workspace (large-window backward only)
     float* dqkv;           // (B, L, 3C)       backward output
     int B, reso, C, heads_total;
+    int hd;                // real head dim (8, 16, 24 or 32); LDS images and MFMA tiles are zero-padded to HD = 32
     float scale;
     int nbranch;
     AttnBranch br[2];
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnPa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int L = p.reso * p.reso, C3 = 3 * p.C;
-    const int ch0 = br.c0 + w.g * HD;           // first channel of this head inside C
+    const int ch0 = br.c0 + w.g * p.hd;           // first channel of this head inside C
     const int N = w.N;
     const float* qkv_b = p.qkv + (long)w.b * L * C3;
 
@@ -104,8 +105,8 @@ __global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnPa
     int lq_pre = 0;
     {
         const int tq = 16 * wave + li;
-        if (wave < NT && tq < N) {
-            lq_pre = token_of(br, w, p.reso, tq);
+        if (wave < NT && tq < N) lq_pre = token_of(br, w, p.reso, tq);
+        if (wave < NT && tq < N && 8 * kq < p.hd) {
             const float* src = qkv_b + (long)lq_pre * C3 + ch0 + 8 * kq;
             q0_pre = *reinterpret_cast<const f32x4*>(src);
             q1_pre = *reinterpret_cast<const f32x4*>(src + 4);
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnPa
     for (int idx = tid; idx < NP * 8; idx += 64 * NW) {
         const int row = idx >> 3, c4 = idx & 7;
         f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
-        if (row < N) {
+        if (row < N && 4 * c4 < p.hd) {
             const float* src = qkv_b + (long)token_of(br, w, p.reso, row) * C3 + ch0 + 4 * c4;
             kv = *reinterpret_cast<const f32x4*>(src + p.C);
             vv = *reinterpret_cast<const f32x4*>(src + 2 * p.C);
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnPa
     for (int i = tid; i < 10 * HD; i += 64 * NW) {
         const int tap = i / HD, ch = i - tap * HD;
         const int cb = ch0 - br.c0 + ch;        // channel inside the branch
-        Wl[i] = tap < 9 ? br.lepe_w[cb * 9 + tap] : br.lepe_b[cb];
+        Wl[i] = ch >= p.hd ? 0.f : (tap < 9 ? br.lepe_w[cb * 9 + tap] : br.lepe_b[cb]);
     }
     __syncthreads();
 
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnPa
                 q0 = f32x4{0.f, 0.f, 0.f, 0.f};
                 q1 = q0;
                 lq = qvalid ? token_of(br, w, p.reso, tq) : 0;
-                if (qvalid) {
+                if (qvalid && 8 * kq < p.hd) {
                     const float* src = qkv_b + (long)lq * C3 + ch0 + 8 * kq;
                     q0 = *reinterpret_cast<const f32x4*>(src);
                     q1 = *reinterpret_cast<const f32x4*>(src + 4);
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnPa
                         }
                     }
                 f32x4 out = o[df] * inv + acc;
-                *reinterpret_cast<f32x4*>(p.y + ((long)w.b * L + lq) * p.C + ch0 + d0) = out;
+                if (d0 < p.hd) *reinterpret_cast<f32x4*>(p.y + ((long)w.b * L + lq) * p.C + ch0 + d0) = out;
             }
             if (kq == 0) p.lse[((long)w.b * p.heads_total + br.head0 + w.g) * L + lq] = mx + __logf(sum);
         }
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int L = p.reso * p.reso, C3 = 3 * p.C;
-    const int ch0 = br.c0 + w.g * HD;
+    const int ch0 = br.c0 + w.g * p.hd;
     const int N = w.N;
     const float* qkv_b = p.qkv + (long)w.b * L * C3;
     const float* dy_b = p.dy + (long)w.b * L * p.C;
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
     for (int idx = tid; idx < NP * 8; idx += NTHREADS) {
         const int row = idx >> 3, c4 = idx & 7;
         f32x4 qv = {0.f, 0.f, 0.f, 0.f}, kv = qv, vv = qv, dv = qv;
-        if (row < N) {
+        if (row < N && 4 * c4 < p.hd) {
             const int l = token_of(br, w, p.reso, row);
             const float* src = qkv_b + (long)l * C3 + ch0 + 4 * c4;
             qv = *reinterpret_cast<const f32x4*>(src);
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
     }
     for (int i = tid; i < 9 * HD; i += NTHREADS) {
         const int tap = i / HD, ch = i - tap * HD;
-        Wl[i] = br.lepe_w[(ch0 - br.c0 + ch) * 9 + tap];
+        Wl[i] = ch < p.hd ? br.lepe_w[(ch0 - br.c0 + ch) * 9 + tap] : 0.f;
     }
     __syncthreads();
 
@@ -370,9 +371,11 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
                         acc += wv * dv;
                     }
                 }
-            float* dst = dqkv_b + (long)lk * C3 + ch0 + d0;
-            *reinterpret_cast<f32x4*>(dst + p.C) = dKt[df] * p.scale;
-            *reinterpret_cast<f32x4*>(dst + 2 * p.C) = acc;
+            if (d0 < p.hd) {
+                float* dst = dqkv_b + (long)lk * C3 + ch0 + d0;
+                *reinterpret_cast<f32x4*>(dst + p.C) = dKt[df] * p.scale;
+                *reinterpret_cast<f32x4*>(dst + 2 * p.C) = acc;
+            }
         }
     }
     __syncthreads();
@@ -394,8 +397,8 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
         const int tq = 16 * qt + li;
         if (tq < N) {
             float* dst = dqkv_b + (long)token_of(br, w, p.reso, tq) * C3 + ch0 + 4 * kq;
-            *reinterpret_cast<f32x4*>(dst) = dQt[0] * p.scale;
-            *reinterpret_cast<f32x4*>(dst + 16) = dQt[1] * p.scale;
+            if (4 * kq < p.hd) *reinterpret_cast<f32x4*>(dst) = dQt[0] * p.scale;
+            if (16 + 4 * kq < p.hd) *reinterpret_cast<f32x4*>(dst + 16) = dQt[1] * p.scale;
         }
     }
 
@@ -473,9 +476,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
         const int bi = (p.nbranch > 1 && hg >= p.br[1].head0) ? 1 : 0;
         const AttnBranch& br = p.br[bi];
         const int g = hg - br.head0;
-        const int ch0 = br.c0 + g * HD + 4 * j, cb = g * HD + 4 * j;
+        const int ch0 = br.c0 + g * p.hd + 4 * j, cb = g * p.hd + 4 * j;
         const int yy = l / p.reso, xx = l - yy * p.reso;
         const int ih = yy / br.H_sp, r = yy - ih * br.H_sp, iw = xx / br.W_sp, c = xx - iw * br.W_sp;
+        if (4 * j < p.hd) {
         f32x4 lepe = *reinterpret_cast<const f32x4*>(br.lepe_b + cb);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
         const f32x4 dv = *reinterpret_cast<const f32x4*>(p.dy + ((long)b * L + l) * p.C + ch0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) part += dv[e] * (yv[e] - lepe[e]);
-        out_idx = item;     // delta layout (B, heads_total, L) == item order
+        }
         out_idx = ((long)b * p.heads_total + hg) * L + l;
     }
     part += __shfl_xor(part, 1, 64);
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int L = p.reso * p.reso, C3 = 3 * p.C, N = w.N;
-    const int ch0 = br.c0 + w.g * HD;
+    const int ch0 = br.c0 + w.g * p.hd;
     const float* qkv_b = p.qkv + (long)w.b * L * C3;
     const float* dy_b = p.dy + (long)w.b * L * p.C;
     float* dqkv_b = p.dqkv + (long)w.b * L * C3;
@@ -525,7 +529,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk
     float kf[8], vf[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) kf[e] = vf[e] = 0.f;
-    if (kvalid) {
+    if (kvalid && 8 * kq < p.hd) {
         const float* src = qkv_b + (long)lk * C3 + ch0 + 8 * kq;
         const f32x4 k0 = *reinterpret_cast<const f32x4*>(src + p.C), k1 = *reinterpret_cast<const f32x4*>(src + p.C + 4);
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 2 * p.C), v1 = *reinterpret_cast<const f32x4*>(src + 2 * p.C + 4);
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk
         for (int idx = tid; idx < 64 * 8; idx += 256) {
             const int row = idx >> 3, c4 = idx & 7, tq = q0 + row;
             f32x4 qv = {0.f, 0.f, 0.f, 0.f}, dv = qv;
-            if (tq < N) {
+            if (tq < N && 4 * c4 < p.hd) {
                 const int l = token_of2(br, w.ih, w.iw, p.reso, tq);
                 qv = *reinterpret_cast<const f32x4*>(qkv_b + (long)l * C3 + ch0 + 4 * c4);
                 dv = *reinterpret_cast<const f32x4*>(dy_b + (long)l * p.C + ch0 + 4 * c4);
@@ -589,14 +593,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk
         const int rr = tk / br.W_sp, cc = tk - rr * br.W_sp;
 #pragma unroll
         for (int df = 0; df < 2; ++df) {
-            const int d0 = 16 * df + 4 * kq, cb = w.g * HD + d0;
+            const int d0 = 16 * df + 4 * kq, cb = w.g * p.hd + d0;
             f32x4 acc = dVt[df];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int r2 = rr - ky + 1, c2 = cc - kx + 1;
-                    if ((unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp) {
+                    if (d0 < p.hd && (unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp) {
                         const int l2 = token_of2(br, w.ih, w.iw, p.reso, r2 * br.W_sp + c2);
                         const f32x4 dv = *reinterpret_cast<const f32x4*>(dy_b + (long)l2 * p.C + ch0 + d0);
                         const int tap = ky * 3 + kx;
@@ -605,8 +609,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk
                     }
                 }
             float* dst = dqkv_b + (long)lk * C3 + ch0 + d0;
-            *reinterpret_cast<f32x4*>(dst + p.C) = dKt[df] * p.scale;
-            *reinterpret_cast<f32x4*>(dst + 2 * p.C) = acc;
+            if (d0 < p.hd) {
+                *reinterpret_cast<f32x4*>(dst + p.C) = dKt[df] * p.scale;
+                *reinterpret_cast<f32x4*>(dst + 2 * p.C) = acc;
+            }
         }
     }
 }
@@ -620,7 +626,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int L = p.reso * p.reso, C3 = 3 * p.C, N = w.N;
-    const int ch0 = br.c0 + w.g * HD;
+    const int ch0 = br.c0 + w.g * p.hd;
     const float* qkv_b = p.qkv + (long)w.b * L * C3;
     const float* dy_b = p.dy + (long)w.b * L * p.C;
     float* dqkv_b = p.dqkv + (long)w.b * L * C3;
@@ -633,21 +639,23 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk)
     for (int e = 0; e < 8; ++e) qr[e] = dor[e] = 0.f;
     float lse_q = INFINITY, del_q = 0.f;
     if (qvalid) {
+        lse_q = p.lse[stat_base + lq];
+        del_q = p.delta[stat_base + lq];
+    }
+    if (qvalid && 8 * kq < p.hd) {
         const float* src = qkv_b + (long)lq * C3 + ch0 + 8 * kq;
         const f32x4 q0 = *reinterpret_cast<const f32x4*>(src), q1 = *reinterpret_cast<const f32x4*>(src + 4);
         const float* dsrc = dy_b + (long)lq * p.C + ch0 + 8 * kq;
         const f32x4 d0 = *reinterpret_cast<const f32x4*>(dsrc), d1 = *reinterpret_cast<const f32x4*>(dsrc + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { qr[e] = q0[e] * p.scale; qr[4 + e] = q1[e] * p.scale; dor[e] = d0[e]; dor[4 + e] = d1[e]; }
-        lse_q = p.lse[stat_base + lq];
-        del_q = p.delta[stat_base + lq];
     }
     f32x4 dQt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     for (int k0 = 0; k0 < N; k0 += 64) {
         for (int idx = tid; idx < 64 * 8; idx += 256) {
             const int row = idx >> 3, c4 = idx & 7, tk = k0 + row;
             f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
-            if (tk < N) {
+            if (tk < N && 4 * c4 < p.hd) {
                 const float* src = qkv_b + (long)token_of2(br, w.ih, w.iw, p.reso, tk) * C3 + ch0 + 4 * c4;
                 kv = *reinterpret_cast<const f32x4*>(src + p.C);
                 vv = *reinterpret_cast<const f32x4*>(src + 2 * p.C);
@@ -680,8 +688,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk)
     }
     if (qvalid) {
         float* dst = dqkv_b + (long)lq * C3 + ch0 + 4 * kq;
-        *reinterpret_cast<f32x4*>(dst) = dQt[0] * p.scale;
-        *reinterpret_cast<f32x4*>(dst + 16) = dQt[1] * p.scale;
+        if (4 * kq < p.hd) *reinterpret_cast<f32x4*>(dst) = dQt[0] * p.scale;
+        if (16 + 4 * kq < p.hd) *reinterpret_cast<f32x4*>(dst + 16) = dQt[1] * p.scale;
     }
 }
 
@@ -692,13 +700,13 @@ __global__ __launch_bounds__(256) void lepe_wgrad_kernel(AttnParams p) {
     const AttnBranch& br = p.br[w.bi];
     const int tid = threadIdx.x, d = tid & 31, tg = tid >> 5;
     const int L = p.reso * p.reso, C3 = 3 * p.C, N = w.N;
-    const int ch0 = br.c0 + w.g * HD;
+    const int ch0 = br.c0 + w.g * p.hd;
     const float* v_b = p.qkv + (long)w.b * L * C3 + 2 * p.C + ch0 + d;
     const float* dy_b = p.dy + (long)w.b * L * p.C + ch0 + d;
     float a[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) a[i] = 0.f;
-    for (int t = tg; t < N; t += 8) {
+    for (int t = tg; t < N && d < p.hd; t += 8) {
         const int rr = t / br.W_sp, cc = t - rr * br.W_sp;
         const float g = dy_b[(long)token_of(br, w, p.reso, t) * p.C];
 #pragma unroll
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(256) void lepe_wgrad_kernel(AttnParams p) {
 
 // dw[cb][tap] / db[cb] = sum over (b, window) of the partial slabs.  One workgroup per (head, tap-or-bias).
 __global__ __launch_bounds__(1024) void lepe_grad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                                 float* __restrict__ db, int heads, int nslab) {
+                                                                 float* __restrict__ db, int heads, int nslab, int hd) {
     __shared__ float red[1024];
     const int g = blockIdx.x / 10, i = blockIdx.x - g * 10;
     const int d = threadIdx.x & 31, sg = threadIdx.x >> 5;
@@ -743,9 +751,11 @@ __global__ __launch_bounds__(1024) void lepe_grad_reduce_kernel(const float* __r
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 32; ++k) t += red[k * 32 + d];
-        const int cb = g * HD + d;
-        if (i < 9) dw[cb * 9 + i] = t;
-        else db[cb] = t;
+        const int cb = g * hd + d;
+        if (d < hd) {
+            if (i < 9) dw[cb * 9 + i] = t;
+            else db[cb] = t;
+        }
     }
 }
 
@@ -796,8 +806,10 @@ int fill_params(AttnParams& p, const char* who, int B, int reso, int C, int nbra
     const int Cb = C / nbranch;
     int heads_total = 0, wg = 0, N0 = -1;
     for (int i = 0; i < nbranch; ++i) {
-        CSWIN_REQUIRE(heads[i] > 0 && Cb == heads[i] * HD, CSWIN_ERR_UNSUPPORTED,
-                      "%s: head dim %d unsupported (only %d)", who, heads[i] > 0 ? Cb / heads[i] : 0, HD);
+        const int hd = heads[i] > 0 ? Cb / heads[i] : 0;
+        CSWIN_REQUIRE(heads[i] > 0 && Cb == heads[i] * hd && hd >= 8 && hd <= HD && hd % 8 == 0 && (i == 0 || hd == p.hd),
+                      CSWIN_ERR_UNSUPPORTED, "%s: head dim %d unsupported (8, 16, 24 or 32, equal in both branches)", who, hd);
+        p.hd = hd;
         int H_sp, W_sp;
         if (idx[i] == -1) { H_sp = reso; W_sp = reso; }
         else if (idx[i] == 0) { H_sp = reso; W_sp = split; }
@@ -819,7 +831,7 @@ int fill_params(AttnParams& p, const char* who, int B, int reso, int C, int nbra
         CSWIN_REQUIRE(N0 == H_sp * W_sp, CSWIN_ERR_SHAPE, "%s: branches with different window sizes", who);
     }
     p.B = B; p.reso = reso; p.C = C; p.heads_total = heads_total; p.nbranch = nbranch;
-    p.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)HD);
+    p.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)p.hd);
     *ntile = (N0 + 15) / 16;
     *nwg = wg;
     return CSWIN_OK;
@@ -940,7 +952,7 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
     for (int i = 0; i < nbranch; ++i) {
         const AttnBranch& br = p.br[i];
         hipLaunchKernelGGL(lepe_grad_reduce_kernel, dim3(br.heads * 10), dim3(1024), 0, st, br.dw_part, dlepe_w[i],
-                           dlepe_b[i], br.heads, B * br.nWin);
+                           dlepe_b[i], br.heads, B * br.nWin, p.hd);
     }
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;

@@ -13,13 +13,20 @@
 
 namespace {
 
+// lanes per (pixel, sub-pixel) item: the largest power of two <= min(Cz / 4, 64); they stride over the Cz / 4 chunks
+__host__ __device__ inline int carafe_lpr(int Cz) {
+    int l = 1;
+    while (2 * l <= Cz / 4 && 2 * l <= 64) l *= 2;
+    return l;
+}
+
 // one group of LPR lanes (Cz = 4*LPR*VPL... here VPL folded into a loop) handles one (low-res pixel, sub-pixel s)
 template <int S>
 __global__ __launch_bounds__(256) void carafe_fwd_kernel(const float* __restrict__ e, const float* __restrict__ z,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           float* __restrict__ wt_save, int B, int H, int W, int Cz) {
     constexpr int S2 = S * S;
-    const int lpr = min(Cz / 4, 64);                 // lanes per item
+    const int lpr = carafe_lpr(Cz);                   // lanes per item
     const int groups = 256 / lpr;
     const int sub = threadIdx.x % lpr, grp = threadIdx.x / lpr;
     const long items = (long)B * H * W * S2;
@@ -70,7 +77,7 @@ __global__ __launch_bounds__(256) void carafe_bwd_e_kernel(const float* __restri
                                                             const float* __restrict__ wt_save, float* __restrict__ de,
                                                             int B, int H, int W, int Cz) {
     constexpr int S2 = S * S;
-    const int lpr = min(Cz / 4, 64);
+    const int lpr = carafe_lpr(Cz);
     const int groups = 256 / lpr;
     const int sub = threadIdx.x % lpr, grp = threadIdx.x / lpr;
     const long items = (long)B * H * W * S2;
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256) void carafe_bwd_z_kernel(const float* __restri
                                                             const float* __restrict__ wt_save, float* __restrict__ dz,
                                                             int B, int H, int W, int Cz) {
     constexpr int S2 = S * S;
-    const int lpr = min(Cz / 4, 64);
+    const int lpr = carafe_lpr(Cz);
     const int groups = 256 / lpr;
     const int sub = threadIdx.x % lpr, grp = threadIdx.x / lpr;
     const long items = (long)B * H * W;
@@ -186,8 +193,7 @@ int grid_for(long items, int groups) {
 
 bool carafe_args_ok(int B, int H, int W, int Cz, int S) {
     if (B <= 0 || H <= 0 || W <= 0 || Cz <= 0 || (S != 2 && S != 4)) return false;
-    int lpr = Cz / 4 < 64 ? Cz / 4 : 64;
-    return Cz % 4 == 0 && lpr > 0 && (lpr & (lpr - 1)) == 0 && 256 % lpr == 0;
+    return Cz % 4 == 0 && Cz >= 4;
 }
 
 }  // namespace
@@ -198,8 +204,8 @@ extern "C" {
 int cswin_carafe_fwd(const float* e, const float* z, const float* bias, float* out, float* wt_save, int B, int H, int W,
                      int Cz, int S, void* stream) {
     CSWIN_REQUIRE(e && z && out, CSWIN_ERR_SHAPE, "carafe_fwd: null pointer");
-    CSWIN_REQUIRE(carafe_args_ok(B, H, W, Cz, S), CSWIN_ERR_UNSUPPORTED, "carafe_fwd: unsupported shape B=%d H=%d W=%d Cz=%d S=%d (Cz/4 must be a power of two, S in {2,4})", B, H, W, Cz, S);
-    const int groups = 256 / (Cz / 4 < 64 ? Cz / 4 : 64);
+    CSWIN_REQUIRE(carafe_args_ok(B, H, W, Cz, S), CSWIN_ERR_UNSUPPORTED, "carafe_fwd: unsupported shape B=%d H=%d W=%d Cz=%d S=%d (Cz %% 4 == 0, S in {2,4})", B, H, W, Cz, S);
+    const int groups = 256 / carafe_lpr(Cz);
     hipStream_t st = (hipStream_t)stream;
     const long items = (long)B * H * W * S * S;
     if (S == 2) hipLaunchKernelGGL(carafe_fwd_kernel<2>, dim3(grid_for(items, groups)), dim3(256), 0, st, e, z, bias, out, wt_save, B, H, W, Cz);
@@ -218,7 +224,7 @@ int cswin_carafe_bwd(const float* dout, const float* z, const float* wt_save, fl
     CSWIN_REQUIRE(dout && z && wt_save && de && dz, CSWIN_ERR_SHAPE, "carafe_bwd: null pointer");
     CSWIN_REQUIRE(carafe_args_ok(B, H, W, Cz, S), CSWIN_ERR_UNSUPPORTED, "carafe_bwd: unsupported shape");
     CSWIN_REQUIRE(!dbias || (workspace && ws_bytes >= cswin_carafe_bwd_workspace(B, H, W, Cz, S)), CSWIN_ERR_WORKSPACE, "carafe_bwd: workspace too small");
-    const int groups = 256 / (Cz / 4 < 64 ? Cz / 4 : 64);
+    const int groups = 256 / carafe_lpr(Cz);
     hipStream_t st = (hipStream_t)stream;
     const long items = (long)B * H * W * S * S, pixels = (long)B * H * W;
     if (S == 2) {

@@ -128,6 +128,113 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
+// ---- any C with C % 4 == 0 (cswin_base: 96, 192, 384, 768): one wave per row, lanes stride over 16-B chunks ----
+constexpr int GEN_MAXV = 4;     // chunks per lane kept in registers: C <= 4 * 64 * GEN_MAXV = 1024
+
+__global__ __launch_bounds__(256) void ln_fwd_generic_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ y,
+                                                              float* __restrict__ mean, float* __restrict__ rstd, int M, int C,
+                                                              float eps) {
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, nchunk = C >> 2;
+    for (long row = (long)blockIdx.x * 4 + wib; row < M; row += (long)gridDim.x * 4) {
+        f32x4 xv[GEN_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < GEN_MAXV; ++v) {
+            const int ch = lane + 64 * v;
+            xv[v] = ch < nchunk ? *reinterpret_cast<const f32x4*>(x + row * C + 4 * ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += xv[v][0] + xv[v][1] + xv[v][2] + xv[v][3];
+        }
+        const float mu = wave_sum(s) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < GEN_MAXV; ++v)
+            if (lane + 64 * v < nchunk) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q += (xv[v][e] - mu) * (xv[v][e] - mu);
+            }
+        const float rs = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+        for (int v = 0; v < GEN_MAXV; ++v) {
+            const int ch = lane + 64 * v;
+            if (ch < nchunk) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * ch), b = *reinterpret_cast<const f32x4*>(beta + 4 * ch);
+                f32x4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = (xv[v][e] - mu) * rs * g[e] + b[e];
+                *reinterpret_cast<f32x4*>(y + row * C + 4 * ch) = o4;
+            }
+        }
+        if (lane == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+    }
+}
+
+// partial[blk][2C]: per-workgroup {sum dy*xhat, sum dy}; LDS accumulators per wave, combined at the end
+__global__ __launch_bounds__(256) void ln_bwd_generic_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                              float* __restrict__ dx, float* __restrict__ partial, int M, int C) {
+    extern __shared__ float red[];        // [4 waves][2C]
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, nchunk = C >> 2;
+    f32x4 dg[GEN_MAXV], db[GEN_MAXV];
+#pragma unroll
+    for (int v = 0; v < GEN_MAXV; ++v) dg[v] = db[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long row = (long)blockIdx.x * 4 + wib; row < M; row += (long)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[GEN_MAXV], gy[GEN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < GEN_MAXV; ++v) {
+            const int ch = lane + 64 * v;
+            xh[v] = gy[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ch < nchunk) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * C + 4 * ch);
+                const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + row * C + 4 * ch);
+                const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * ch);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[v][e] = (xv[e] - mu) * rs;
+                    gy[v][e] = dv[e] * g[e];
+                    s1 += gy[v][e];
+                    s2 += gy[v][e] * xh[v][e];
+                    dg[v][e] += dv[e] * xh[v][e];
+                    db[v][e] += dv[e];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / C;
+        s2 = wave_sum(s2) / C;
+#pragma unroll
+        for (int v = 0; v < GEN_MAXV; ++v) {
+            const int ch = lane + 64 * v;
+            if (ch < nchunk) {
+                f32x4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = rs * (gy[v][e] - s1 - xh[v][e] * s2);
+                if (dres) o4 += *reinterpret_cast<const f32x4*>(dres + row * C + 4 * ch);
+                *reinterpret_cast<f32x4*>(dx + row * C + 4 * ch) = o4;
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < GEN_MAXV; ++v) {
+        const int ch = lane + 64 * v;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[wib * 2 * C + 4 * ch + e] = dg[v][e];
+                red[wib * 2 * C + C + 4 * ch + e] = db[v][e];
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += 256)
+        partial[(long)blockIdx.x * 2 * C + c] = red[c] + red[2 * C + c] + red[4 * C + c] + red[6 * C + c];
+}
+
 int ln_grid(int M, int rpb) { return min(cdiv(M, rpb), 512); }
 
 template <int LPR, int VPL>
@@ -141,7 +248,8 @@ void launch_bwd(const float* dy, const float* x, const float* mean, const float*
     hipLaunchKernelGGL((ln_bwd_kernel<LPR, VPL>), dim3(ln_grid(M, 256 / LPR)), dim3(256), 0, st, dy, x, mean, rstd, g, dres, dx, partial, M);
 }
 
-bool ln_supported(int C) { return C == 64 || C == 128 || C == 256 || C == 512 || C == 32 || C == 1024; }
+bool ln_fast(int C) { return C == 64 || C == 128 || C == 256 || C == 512 || C == 32 || C == 1024; }
+bool ln_supported(int C) { return C > 0 && C % 4 == 0 && C <= 256 * GEN_MAXV; }
 
 }  // namespace
 
@@ -150,8 +258,13 @@ extern "C" {
 int cswin_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                         int M, int C, float eps, void* stream) {
     CSWIN_REQUIRE(x && gamma && beta && y && mean && rstd && M > 0, CSWIN_ERR_SHAPE, "layernorm_fwd: bad arguments");
-    CSWIN_REQUIRE(ln_supported(C), CSWIN_ERR_UNSUPPORTED, "layernorm: C=%d not in {32,64,128,256,512,1024}", C);
+    CSWIN_REQUIRE(ln_supported(C), CSWIN_ERR_UNSUPPORTED, "layernorm: C=%d must be a multiple of 4, at most 1024", C);
     hipStream_t st = (hipStream_t)stream;
+    if (!ln_fast(C)) {
+        hipLaunchKernelGGL(ln_fwd_generic_kernel, dim3(ln_grid(M, 4)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, C, eps);
+        CSWIN_LAUNCH_CHECK();
+        return CSWIN_OK;
+    }
     switch (C) {
         case 32: launch_fwd<8, 1>(x, gamma, beta, y, mean, rstd, M, eps, st); break;
         case 64: launch_fwd<16, 1>(x, gamma, beta, y, mean, rstd, M, eps, st); break;
@@ -165,6 +278,7 @@ int cswin_layernorm_fwd(const float* x, const float* gamma, const float* beta, f
 }
 
 size_t cswin_layernorm_bwd_workspace(int M, int C) {
+    if (!ln_fast(C)) return (size_t)ln_grid(M, 4) * 2 * C * sizeof(float);
     int lpr = C / 4 > 64 ? 64 : C / 4;
     return (size_t)ln_grid(M, 256 / lpr) * 2 * C * sizeof(float);
 }
@@ -174,13 +288,15 @@ int cswin_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
                         const float* dres, float* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes,
                         int M, int C, cswin_reduce_job* deferred, void* stream) {
     CSWIN_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && M > 0, CSWIN_ERR_SHAPE, "layernorm_bwd: bad arguments");
-    CSWIN_REQUIRE(ln_supported(C), CSWIN_ERR_UNSUPPORTED, "layernorm: C=%d not in {32,64,128,256,512,1024}", C);
+    CSWIN_REQUIRE(ln_supported(C), CSWIN_ERR_UNSUPPORTED, "layernorm: C=%d must be a multiple of 4, at most 1024", C);
     CSWIN_REQUIRE(workspace && ws_bytes >= cswin_layernorm_bwd_workspace(M, C), CSWIN_ERR_WORKSPACE, "layernorm_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)workspace;
     int lpr = C / 4 > 64 ? 64 : C / 4;
-    int nblk = ln_grid(M, 256 / lpr);
-    switch (C) {
+    int nblk = ln_fast(C) ? ln_grid(M, 256 / lpr) : ln_grid(M, 4);
+    if (!ln_fast(C))
+        hipLaunchKernelGGL(ln_bwd_generic_kernel, dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), st, dy, x, mean, rstd, gamma, dres, dx, partial, M, C);
+    else switch (C) {
         case 32: launch_bwd<8, 1>(dy, x, mean, rstd, gamma, dres, dx, partial, M, st); break;
         case 64: launch_bwd<16, 1>(dy, x, mean, rstd, gamma, dres, dx, partial, M, st); break;
         case 128: launch_bwd<32, 1>(dy, x, mean, rstd, gamma, dres, dx, partial, M, st); break;

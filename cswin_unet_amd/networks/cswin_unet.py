@@ -244,9 +244,11 @@ class CSWinTransformer(nn.Module):
         self.upsample2 = CARAFE(2 * E, E)
         self.concat_linear2 = nn.Linear(2 * E, E)
         self.stage_up1 = make_stage(0)
-        self.upsample1 = CARAFE4(E, 64)
+        # reference hard-codes 64 here and E in `output` (cswin_unet.py:437-439), which only agree for E = 64;
+        # E is used for both so that embed_dim != 64 (cswin_base) is a consistent model
+        self.upsample1 = CARAFE4(E, E)
         self.norm_up = norm_layer(E)
-        self.output = nn.Conv2d(in_channels=64, out_channels=self.num_classes, kernel_size=1, bias=False)
+        self.output = nn.Conv2d(in_channels=E, out_channels=self.num_classes, kernel_size=1, bias=False)
 
         self.apply(self._init_weights)
 

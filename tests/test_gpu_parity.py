@@ -194,6 +194,33 @@ def test_attention_384_fwd_bwd_vs_golden(N, golden, reso, idx, split, dim, heads
             f.write(f"attn384_golden.{key}.{name}: {err:.3e}\n")
 
 
+@pytest.mark.parametrize("reso,idx,split,dim,heads", [(56, 0, 1, 48, 2), (28, 1, 2, 96, 4), (14, 0, 7, 192, 8),
+                                                        (7, -1, 7, 384, 16), (24, 1, 12, 192, 8), (28, 0, 2, 32, 2),
+                                                        (14, 1, 7, 32, 4)])
+def test_attention_other_head_dims_vs_oracle(N, reso, idx, split, dim, heads):
+    """Head dims 24 (cswin_base: embed_dim 96), 16 and 8.  The reference cannot build these models (its decoder widths are
+    hard-coded for embed_dim 64, cswin_unet.py:404-439), so this case is pinned against the oracle only."""
+    key = f"hd.r{reso}_i{idx}_s{split}_c{dim}"
+    L = reso * reso
+    att = N.LePEAttention(dim, resolution=reso, idx=idx, split_size=split, num_heads=heads).to(DEV)
+    fill_state_dict(att, prefix=f"attn.{key}.")
+    qkv = [det_normal(f"attn.{key}.{n}", (2, L, dim)) for n in "qkv"]
+    dy = det_normal(f"attn.{key}.dy", (2, L, dim))
+    dev = [T(a, True) for a in qkv]
+    y = att(dev)
+    y.backward(T(dy))
+    ref = [torch.from_numpy(a).requires_grad_() for a in qkv]
+    w = att.get_v.weight.detach().cpu().clone().requires_grad_()
+    b = att.get_v.bias.detach().cpu().clone().requires_grad_()
+    yr = O.lepe_attention(*ref, w, b, reso, idx, split, heads)
+    yr.backward(torch.from_numpy(dy))
+    rel_err(y, yr, key + ".y")
+    for n, d, r in zip(("dq", "dk", "dv"), dev, ref):
+        rel_err(d.grad, r.grad, f"{key}.{n}")
+    rel_err(att.get_v.weight.grad, w.grad, key + ".dw")
+    rel_err(att.get_v.bias.grad, b.grad, key + ".db")
+
+
 @pytest.mark.parametrize("dim,reso,heads,split,last", [(64, 56, 2, 1, False), (128, 28, 4, 2, False),
                                                         (256, 14, 8, 7, False), (512, 7, 16, 7, True)])
 def test_block_vs_golden(N, golden, dim, reso, heads, split, last):
@@ -451,3 +478,29 @@ def test_model_384_training_step_vs_oracle(N, ops, golden):
     for n in ["stage3.4.qkv.weight", "stage3.4.attns.1.get_v.weight", "stage4.0.attns.0.get_v.bias", "stage_up3.2.proj.weight",
               "stage1_conv_embed.0.weight", "merge2.conv.weight", "upsample1.encoder.weight", "output.weight"]:
         rel_err(params[n].grad, P[n].grad, "model384.grad." + n)
+
+
+def test_model_base_width_training_step_vs_oracle(N, ops):
+    """cswin_base widths (embed_dim 96 -> channels 96/192/384/768, head dim 24, heads [4,8,16,32]) with a short depth, one
+    training step at B=2 vs the CPU oracle.  Exercises the generic-C LayerNorm, head-dim-24 attention, CARAFE with
+    Cz/4 not a power of two and GEMMs with K, N multiples of 96.  Pinned against the oracle only: the reference model
+    cannot be constructed for embed_dim != 64 (cswin_unet.py:404-439 hard-code the decoder widths)."""
+    cfg = dict(O.TINY_224, embed_dim=96, depth=(1, 2, 2, 1), num_heads=(4, 8, 16, 32))
+    net = N.CSWinTransformer(img_size=224, num_classes=9, embed_dim=96, depth=[1, 2, 2, 1], split_size=[1, 2, 7, 7],
+                             num_heads=[4, 8, 16, 32], qkv_bias=True).to(DEV)
+    fill_state_dict(net).train()
+    img = det_normal("modelbase.x", (2, 3, 224, 224))
+    lab = det_labels("modelbase.lab", (2, 224, 224), 9)
+    logits = net(T(img))
+    loss, _ = ops.ce_dice_loss(logits, T(lab))
+    loss.backward()
+    P = O.golden_params(cfg)
+    ref_logits = O.cswin_forward(P, torch.from_numpy(img), cfg)
+    ref_loss, _, _ = O.ce_dice_loss(ref_logits, torch.from_numpy(lab))
+    ref_loss.backward()
+    rel_err(logits, ref_logits, "modelbase.logits")
+    assert abs(float(loss) - float(ref_loss)) < 1e-3 * abs(float(ref_loss))
+    params = dict(net.named_parameters())
+    assert set(params) == set(P)
+    for n in params:
+        rel_err(params[n].grad, P[n].grad, "modelbase.grad." + n)
