@@ -18,6 +18,7 @@
 // LDS once for dQ, LePE^T(dO) is added to dV, and the depthwise-conv weight/bias gradients are
 // written as per-workgroup partial slabs (reduced deterministically by a second tiny kernel).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -904,9 +905,9 @@ size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* 
     AttnParams p = {};
     int nt, nwg;
     if (fill_params(p, "attn_bwd_workspace", B, reso, C, nbranch, heads, idx, split, 0.f, &nt, &nwg)) return 0;
-    // LePE partial slabs + (windows > 112 tokens only) delta (B, heads, L)
+    // LePE partial slabs + delta (B, heads, L) (used by the two-pass path)
     size_t n = (size_t)nwg * 10 * HD;
-    if (nt > 7) n += (size_t)B * p.heads_total * reso * reso;
+    n += (size_t)B * p.heads_total * reso * reso;
     return n * sizeof(float);
 }
 
@@ -930,7 +931,8 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
     p.delta = (float*)workspace + (size_t)nwg * 10 * HD;
     p.qkv = qkv; p.lse = const_cast<float*>(lse); p.dy = dy; p.dqkv = dqkv;
     hipStream_t st = (hipStream_t)stream;
-    if (nt > 7) {
+    static const bool force_two_pass = getenv("CSWIN_ATTN_BWD_TWO_PASS") != nullptr;     // tuning aid
+    if (nt > 7 || force_two_pass) {
         // windows of more than 112 tokens (384x384: N = 144, 288): two-pass path, needs the forward output and the LePE bias
         CSWIN_REQUIRE(y && lepe_b, CSWIN_ERR_SHAPE, "attn_bwd: windows of %d tokens need y and lepe_b (large-window path)", p.br[0].H_sp * p.br[0].W_sp);
         const int N = p.br[0].H_sp * p.br[0].W_sp, nblk = (N + 63) / 64;

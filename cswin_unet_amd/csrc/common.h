@@ -55,57 +55,74 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
-// out[i] = sum_r part[r * stride + i], i < n  (deterministic order).  32 columns x G row-groups per workgroup so that
-// partial-slab reductions (split-K weight gradients, LayerNorm dgamma/dbeta, loss sums, bias sums) are parallel over
-// the slabs instead of one serial chain per column (G = 8 for few slabs, 32 for many; two loads in flight per thread).
-// Columns >= n_first go to out2[i - n_first] when out2 != NULL.
-template <int G>
-static __global__ __launch_bounds__(32 * G) void rows_sum_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                                  float* __restrict__ out2, long n_first, long n, int rows,
-                                                                  long stride) {
-    __shared__ float red[G][33];
-    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const long i = (long)blockIdx.x * 32 + c;
-    float s0 = 0.f, s1 = 0.f;
-    if (i < n) {
-        int r = g;
-        for (; r + G < rows; r += 2 * G) {
-            s0 += part[(long)r * stride + i];
-            s1 += part[(long)(r + G) * stride + i];
-        }
-        if (r < rows) s0 += part[(long)r * stride + i];
-    }
-    red[g][c] = s0 + s1;
-    __syncthreads();
-    if (g == 0 && i < n) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < G; ++k) t += red[k][c];
-        if (out2 && i >= n_first) out2[i - n_first] = t;
-        else out[i] = t;
-    }
-}
-
-static inline void launch_rows_sum(const float* part, float* out, float* out2, long n_first, long n, int rows, long stride,
-                                   hipStream_t st) {
-    const unsigned blocks = (unsigned)((n + 31) / 32);
-    if (rows > 48)
-        hipLaunchKernelGGL(rows_sum_kernel<32>, dim3(blocks), dim3(1024), 0, st, part, out, out2, n_first, n, rows, stride);
-    else
-        hipLaunchKernelGGL(rows_sum_kernel<8>, dim3(blocks), dim3(256), 0, st, part, out, out2, n_first, n, rows, stride);
-}
-
-// ---- deferred slab reductions: several producers' partial slabs reduced by ONE launch ----------------------------
-// (a CSWinBlock backward has six: four split-K weight gradients and two LayerNorm dgamma/dbeta; as separate launches
-// each costs ~5 us of pure launch latency)
+// ---- partial-slab reductions ------------------------------------------------------------------------------------
+// out[i] = sum_r part[r * stride + i], i < n, in a fixed order (deterministic).  Used for split-K weight gradients,
+// LayerNorm dgamma/dbeta, loss sums and bias sums.  Columns >= n_first go to out2[i - n_first] when out2 != NULL.
+// Several producers' slabs can be reduced by ONE launch (a CSWinBlock backward has six: four split-K weight gradients
+// and two LayerNorm dgamma/dbeta; as separate launches each costs ~5 us of pure launch latency).
 extern "C" {
 typedef struct cswin_reduce_job {
     const float* part;       // [rows][stride] partial slabs
     float* out;              // columns [0, n_first)
     float* out2;             // columns [n_first, n) (may be NULL: then everything goes to out)
     long long n_first, n, stride;
-    int rows, reserved;
+    int rows, reserved;      // reserved: set by the library (bit 0 = 16-B loads are legal)
 } cswin_reduce_job;
+}
+
+static inline int reduce_job_vec_ok(const cswin_reduce_job& j) {
+    return ((uintptr_t)j.part % 16 == 0) && j.stride % 4 == 0 && j.n % 4 == 0 && (!j.out2 || j.n_first % 4 == 0);
+}
+
+// One workgroup (256 threads) = 64 columns x 16 row groups: a wave reads 4 slab rows x 256 contiguous bytes per
+// instruction with up to four 16-B loads in flight per lane; the 16 row-group sums meet in LDS.
+constexpr int RS_COLS = 64, RS_G = 16;
+__device__ __forceinline__ void rows_sum_block(const cswin_reduce_job& job, long blk, float (*red)[RS_COLS + 1]) {
+    const int c4 = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const long i0 = blk * RS_COLS + 4 * c4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (i0 < job.n) {
+        const float* base = job.part + i0;
+        if (job.reserved & 1) {
+            int r = g;
+            for (; r + 3 * RS_G < job.rows; r += 4 * RS_G) {
+                s0 += *reinterpret_cast<const f32x4*>(base + (long)r * job.stride);
+                s1 += *reinterpret_cast<const f32x4*>(base + (long)(r + RS_G) * job.stride);
+                s2 += *reinterpret_cast<const f32x4*>(base + (long)(r + 2 * RS_G) * job.stride);
+                s3 += *reinterpret_cast<const f32x4*>(base + (long)(r + 3 * RS_G) * job.stride);
+            }
+            for (; r < job.rows; r += RS_G) s0 += *reinterpret_cast<const f32x4*>(base + (long)r * job.stride);
+        } else {
+            for (int r = g; r < job.rows; r += RS_G)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (i0 + e < job.n) s0[e] += base[(long)r * job.stride + e];
+        }
+    }
+    s0 = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[g][4 * c4 + e] = s0[e];
+    __syncthreads();
+    const long i = blk * RS_COLS + threadIdx.x;
+    if (threadIdx.x < RS_COLS && i < job.n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < RS_G; ++k) t += red[k][threadIdx.x];
+        if (job.out2 && i >= job.n_first) job.out2[i - job.n_first] = t;
+        else job.out[i] = t;
+    }
+}
+
+static __global__ __launch_bounds__(256) void rows_sum_kernel(cswin_reduce_job job) {
+    __shared__ float red[RS_G][RS_COLS + 1];
+    rows_sum_block(job, blockIdx.x, red);
+}
+
+static inline void launch_rows_sum(const float* part, float* out, float* out2, long n_first, long n, int rows, long stride,
+                                   hipStream_t st) {
+    cswin_reduce_job job = {part, out, out2, n_first, n, stride, rows, 0};
+    job.reserved = reduce_job_vec_ok(job);
+    hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((n + RS_COLS - 1) / RS_COLS)), dim3(256), 0, st, job);
 }
 
 constexpr int CSWIN_MAX_REDUCE_JOBS = 8;
@@ -115,32 +132,11 @@ struct ReduceJobs {
     int njobs;
 };
 
-static __global__ __launch_bounds__(512) void rows_sum_multi_kernel(ReduceJobs J) {
-    constexpr int G = 16;
-    __shared__ float red[G][33];
+static __global__ __launch_bounds__(256) void rows_sum_multi_kernel(ReduceJobs J) {
+    __shared__ float red[RS_G][RS_COLS + 1];
     int k = 0;
     while (k + 1 < J.njobs && (int)blockIdx.x >= J.first_block[k + 1]) ++k;
-    const cswin_reduce_job job = J.j[k];
-    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const long i = (long)(blockIdx.x - J.first_block[k]) * 32 + c;
-    float s0 = 0.f, s1 = 0.f;
-    if (i < job.n) {
-        int r = g;
-        for (; r + G < job.rows; r += 2 * G) {
-            s0 += job.part[(long)r * job.stride + i];
-            s1 += job.part[(long)(r + G) * job.stride + i];
-        }
-        if (r < job.rows) s0 += job.part[(long)r * job.stride + i];
-    }
-    red[g][c] = s0 + s1;
-    __syncthreads();
-    if (g == 0 && i < job.n) {
-        float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < G; ++q) t += red[q][c];
-        if (job.out2 && i >= job.n_first) job.out2[i - job.n_first] = t;
-        else job.out[i] = t;
-    }
+    rows_sum_block(J.j[k], blockIdx.x - J.first_block[k], red);
 }
 
 // run `job` now, or hand it to the caller (deferred != NULL) to be batched by cswin_rows_sum_multi

@@ -804,12 +804,13 @@ int cswin_rows_sum_multi(const cswin_reduce_job* jobs, int njobs, void* stream) 
     for (int i = 0; i < njobs; ++i) {
         CSWIN_REQUIRE(jobs[i].part && jobs[i].out && jobs[i].n > 0 && jobs[i].rows > 0, CSWIN_ERR_SHAPE, "rows_sum_multi: bad job %d", i);
         J.j[i] = jobs[i];
+        J.j[i].reserved = reduce_job_vec_ok(jobs[i]);
         J.first_block[i] = blocks;
-        blocks += (int)((jobs[i].n + 31) / 32);
+        blocks += (int)((jobs[i].n + RS_COLS - 1) / RS_COLS);
     }
     J.first_block[njobs] = blocks;
     J.njobs = njobs;
-    hipLaunchKernelGGL(rows_sum_multi_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, J);
+    hipLaunchKernelGGL(rows_sum_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, J);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }
