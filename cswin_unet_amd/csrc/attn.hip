@@ -33,7 +33,8 @@ struct AttnBranch {
     int wg_begin;    // first workgroup of this branch
     const float* lepe_w;   // [Cb][9]
     const float* lepe_b;   // [Cb]
-    float* dw_part;        // backward: [wg_local][10][32] partial slabs (9 taps + bias)
+    float* dw_part;        // backward: partial slabs [b * nWin + win][Cb * 9 (channel-major, tap minor) | Cb] of the
+                           // LePE conv weight / bias gradient: a standard cswin_reduce_job over B * nWin rows
 };
 
 struct AttnParams {
@@ -48,6 +49,7 @@ struct AttnParams {
     int hd;                // real head dim (8, 16, 24 or 32); LDS images and MFMA tiles are zero-padded to HD = 32
     float scale;
     int nbranch;
+    long long* stamps;     // debug (cswin_debug_set_attn_stamps): [workgroup][8] s_memtime stamps of wave 0, or NULL
     AttnBranch br[2];
 };
 
@@ -75,6 +77,22 @@ __device__ __forceinline__ int token_of(const AttnBranch& br, const WgInfo& w, i
     int r = t / br.W_sp, c = t - r * br.W_sp;
     return (w.ih * br.H_sp + r) * reso + w.iw * br.W_sp + c;
 }
+
+// partial-slab row of workgroup (b, win, head g): element i = tap * HD + d of the [10][HD] scratch (tap 9 = bias)
+__device__ __forceinline__ void store_lepe_partial(const AttnParams& p, const AttnBranch& br, const WgInfo& w, int i, float v) {
+    const int tap = i / HD, d = i - tap * HD;
+    if (d >= p.hd) return;
+    const int cb = br.heads * p.hd;                         // channels of this branch
+    float* row = br.dw_part + ((long)w.b * br.nWin + w.win) * (cb * 10);
+    const int ch = w.g * p.hd + d;
+    if (tap < 9) row[ch * 9 + tap] = v;
+    else row[cb * 9 + ch] = v;
+}
+
+#define ATTN_STAMP(k)                                                                                   \
+    do {                                                                                                \
+        if (p.stamps && threadIdx.x == 0) p.stamps[(long)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -211,12 +229,12 @@ __global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnPa
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
+                        // clamped address + select instead of a branch: all 9 taps' LDS reads are in flight together
                         const int r2 = rr + ky - 1, c2 = cc + kx - 1;
-                        if ((unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp) {
-                            const f32x4 wv = *reinterpret_cast<const f32x4*>(&Wl[(ky * 3 + kx) * HD + d0]);
-                            const f32x4 vv = *reinterpret_cast<const f32x4*>(&Vs[(r2 * br.W_sp + c2) * LDT + d0]);
-                            acc += wv * vv;
-                        }
+                        const bool ok = (unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp;
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(&Wl[(ky * 3 + kx) * HD + d0]);
+                        const f32x4 vv = *reinterpret_cast<const f32x4*>(&Vs[(ok ? r2 * br.W_sp + c2 : tq) * LDT + d0]);
+                        acc += (ok ? 1.f : 0.f) * wv * vv;
                     }
                 f32x4 out = o[df] * inv + acc;
                 if (d0 < p.hd) *reinterpret_cast<f32x4*>(p.y + ((long)w.b * L + lq) * p.C + ch0 + d0) = out;
@@ -266,6 +284,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
     float* dqkv_b = p.dqkv + (long)w.b * L * C3;
     const float* lse_b = p.lse + ((long)w.b * p.heads_total + br.head0 + w.g) * L;
 
+    ATTN_STAMP(0);
     for (int idx = tid; idx < NP * 8; idx += NTHREADS) {
         const int row = idx >> 3, c4 = idx & 7;
         f32x4 qv = {0.f, 0.f, 0.f, 0.f}, kv = qv, vv = qv, dv = qv;
@@ -291,6 +310,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
         Wl[i] = ch < p.hd ? br.lepe_w[(ch0 - br.c0 + ch) * 9 + tap] : 0.f;
     }
     __syncthreads();
+    ATTN_STAMP(1);
 
     // ---- this wave's 16 keys: K and V fragments (B operands, key on the lane) ----
     const int kw = wave;                               // key tile owned by this wave
@@ -330,6 +350,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
         P[qt] = sa;
         dP[qt] = da;
     }
+    ATTN_STAMP(2);
     __syncthreads();
 
     // ---- loop 2: dS = P o (dP - delta); dV^T += dO^T P; dK^T += Q^T dS; dS -> LDS ----
@@ -366,11 +387,10 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int r2 = rr - ky + 1, c2 = cc - kx + 1;   // output position that read this key through tap (ky,kx)
-                    if ((unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp) {
-                        const f32x4 wv = *reinterpret_cast<const f32x4*>(&Wl[(ky * 3 + kx) * HD + d0]);
-                        const f32x4 dv = *reinterpret_cast<const f32x4*>(&Ds[(r2 * br.W_sp + c2) * LDT + d0]);
-                        acc += wv * dv;
-                    }
+                    const bool ok = (unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp;
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(&Wl[(ky * 3 + kx) * HD + d0]);
+                    const f32x4 dv = *reinterpret_cast<const f32x4*>(&Ds[(ok ? r2 * br.W_sp + c2 : tk) * LDT + d0]);
+                    acc += (ok ? 1.f : 0.f) * wv * dv;
                 }
             if (d0 < p.hd) {
                 float* dst = dqkv_b + (long)lk * C3 + ch0 + d0;
@@ -379,6 +399,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
             }
         }
     }
+    ATTN_STAMP(3);
     __syncthreads();
 
     // ---- phase 3: dQ^T[d][q] = scale * sum_key K[key][d] dS[q][key]; this wave owns query tile `wave` ----
@@ -402,16 +423,18 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
             if (16 + 4 * kq < p.hd) *reinterpret_cast<f32x4*>(dst + 16) = dQt[1] * p.scale;
         }
     }
+    ATTN_STAMP(4);
 
     // ---- LePE weight / bias gradient partials of this (window, head): dw[tap][d], db[d] ----
-    // Qs is dead after loop 2 (barrier above): reuse it as [8][10][32] scratch.
+    // Qs is dead after loop 2 (barrier above): reuse it as [NT waves][10][32] scratch.  Half-wave h of wave w takes
+    // tokens 2w + h, 2w + h + 2 NT, ...; the two halves meet through one cross-half shuffle.
     float* scratch = Qs;
-    if (tid < 256) {
-        const int d = tid & 31, tg = tid >> 5;
+    {
+        const int d = lane & 31;
         float a[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) a[i] = 0.f;
-        for (int t = tg; t < N; t += 8) {
+        for (int t = 2 * wave + (lane >> 5); t < N; t += 2 * NT) {
             const float g = Ds[t * LDT + d];
             const int rr = t / br.W_sp, cc = t - rr * br.W_sp;
 #pragma unroll
@@ -419,21 +442,27 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int r2 = rr + ky - 1, c2 = cc + kx - 1;
-                    if ((unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp)
-                        a[ky * 3 + kx] += g * Vs[(r2 * br.W_sp + c2) * LDT + d];
+                    const bool ok = (unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp;
+                    const float vv = Vs[(ok ? r2 * br.W_sp + c2 : t) * LDT + d];
+                    a[ky * 3 + kx] += ok ? g * vv : 0.f;
                 }
             a[9] += g;
         }
 #pragma unroll
-        for (int i = 0; i < 10; ++i) scratch[(tg * 10 + i) * HD + d] = a[i];
+        for (int i = 0; i < 10; ++i) {
+            a[i] += __shfl_xor(a[i], 32, 64);
+            if (lane < 32) scratch[(wave * 10 + i) * HD + d] = a[i];
+        }
     }
+    ATTN_STAMP(5);
     __syncthreads();
     for (int i = tid; i < 10 * HD; i += NTHREADS) {
-        float s = 0.f;
+        float sum = 0.f;
 #pragma unroll
-        for (int tg = 0; tg < 8; ++tg) s += scratch[tg * 10 * HD + i];
-        br.dw_part[(long)(blockIdx.x - br.wg_begin) * 10 * HD + i] = s;
+        for (int k = 0; k < NT; ++k) sum += scratch[k * 10 * HD + i];
+        store_lepe_partial(p, br, w, i, sum);
     }
+    ATTN_STAMP(6);
 }
 
 // =====================================================================================
@@ -727,36 +756,7 @@ __global__ __launch_bounds__(256) void lepe_wgrad_kernel(AttnParams p) {
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) s += scratch[k * 10 * HD + i];
-        br.dw_part[(long)(blockIdx.x - br.wg_begin) * 10 * HD + i] = s;
-    }
-}
-
-// dw[cb][tap] / db[cb] = sum over (b, window) of the partial slabs.  One workgroup per (head, tap-or-bias).
-__global__ __launch_bounds__(1024) void lepe_grad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                                 float* __restrict__ db, int heads, int nslab, int hd) {
-    __shared__ float red[1024];
-    const int g = blockIdx.x / 10, i = blockIdx.x - g * 10;
-    const int d = threadIdx.x & 31, sg = threadIdx.x >> 5;
-    const long stride = (long)heads * 10 * HD;
-    const float* base = part + (long)g * 10 * HD + i * HD + d;
-    float s0 = 0.f, s1 = 0.f;
-    int sl = sg;
-    for (; sl + 32 < nslab; sl += 64) {
-        s0 += base[sl * stride];
-        s1 += base[(sl + 32) * stride];
-    }
-    if (sl < nslab) s0 += base[sl * stride];
-    red[threadIdx.x] = s0 + s1;
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) t += red[k * 32 + d];
-        const int cb = g * hd + d;
-        if (d < hd) {
-            if (i < 9) dw[cb * 9 + i] = t;
-            else db[cb] = t;
-        }
+        store_lepe_partial(p, br, w, i, s);
     }
 }
 
@@ -870,9 +870,14 @@ int launch_bwd(const AttnParams& p, int nwg, hipStream_t st) {
     return CSWIN_OK;
 }
 
+long long* g_attn_stamps = nullptr;     // debug only (cswin_debug_set_attn_stamps)
+
 }  // namespace
 
 extern "C" {
+
+// debug aid (not part of include/cswin_hip.h): device buffer [workgroups][8] of int64 stamped by attn_bwd_kernel wave 0
+void cswin_debug_set_attn_stamps(void* p) { g_attn_stamps = (long long*)p; }
 
 // qkv (B, L, 3C) -> y (B, L, C), lse (B, heads_total, L).  nbranch = 2: branch i uses channels
 // [i*C/2, (i+1)*C/2) with stripe mode idx[i]; nbranch = 1: whole C, idx[0] (normally -1).
@@ -915,7 +920,7 @@ size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* 
 int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, const float* lse,
                    const float* y, const float* dy, float* dqkv, float* const* dlepe_w, float* const* dlepe_b,
                    void* workspace, size_t ws_bytes, int B, int reso, int C, int nbranch, const int* heads, const int* idx,
-                   int split, float scale, void* stream) {
+                   int split, float scale, cswin_reduce_job* deferred, void* stream) {
     AttnParams p = {};
     int nt, nwg;
     int rc = fill_params(p, "attn_bwd", B, reso, C, nbranch, heads, idx, split, scale, &nt, &nwg);
@@ -927,6 +932,7 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
         p.br[i].lepe_b = lepe_b ? lepe_b[i] : nullptr;
         p.br[i].dw_part = (float*)workspace + (size_t)p.br[i].wg_begin * 10 * HD;
     }
+    p.stamps = g_attn_stamps;
     p.y_in = y;
     p.delta = (float*)workspace + (size_t)nwg * 10 * HD;
     p.qkv = qkv; p.lse = const_cast<float*>(lse); p.dy = dy; p.dqkv = dqkv;
@@ -951,12 +957,28 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
     }
     if (rc) return rc;
     CSWIN_LAUNCH_CHECK();
+    // the slabs of each branch are a standard reduction job: rows = B * nWin, columns = [Cb * 9 | Cb]
+    ReduceJobs J = {};
+    int blocks = 0;
     for (int i = 0; i < nbranch; ++i) {
         const AttnBranch& br = p.br[i];
-        hipLaunchKernelGGL(lepe_grad_reduce_kernel, dim3(br.heads * 10), dim3(1024), 0, st, br.dw_part, dlepe_w[i],
-                           dlepe_b[i], br.heads, B * br.nWin, p.hd);
+        const long cb = (long)br.heads * p.hd;
+        cswin_reduce_job job = {br.dw_part, dlepe_w[i], dlepe_b[i], cb * 9, cb * 10, cb * 10, B * br.nWin, 0};
+        if (deferred) {
+            deferred[i] = job;
+            continue;
+        }
+        job.reserved = reduce_job_vec_ok(job);
+        J.j[i] = job;
+        J.first_block[i] = blocks;
+        blocks += (int)((job.n + RS_COLS - 1) / RS_COLS);
     }
-    CSWIN_LAUNCH_CHECK();
+    if (!deferred) {
+        J.first_block[nbranch] = blocks;
+        J.njobs = nbranch;
+        hipLaunchKernelGGL(rows_sum_multi_kernel, dim3(blocks), dim3(256), 0, st, J);
+        CSWIN_LAUNCH_CHECK();
+    }
     return CSWIN_OK;
 }
 

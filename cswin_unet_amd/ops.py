@@ -299,7 +299,7 @@ class _StripeAttention(Function):
         nbytes = lib().cswin_attn_bwd_workspace(B, reso, C, nb, ha, ia, split)
         ws = _ws(nbytes, qkv.device)
         call("cswin_attn_bwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(lse), ptr(y), ptr(dy), ptr(dqkv), _ptr_array(dws),
-             _ptr_array(dbs), ptr(ws), nbytes, B, reso, C, nb, ha, ia, split, scale, stream())
+             _ptr_array(dbs), ptr(ws), nbytes, B, reso, C, nb, ha, ia, split, scale, None, stream())
         return (dqkv, None, None, None, None, None) + tuple(d.view(d.shape[0], 1, 3, 3) for d in dws) + tuple(dbs)
 
 
@@ -364,14 +364,15 @@ class _CSWinBlock(Function):
         M, Hd, nb = B * L, w1.shape[0], len(idx)
         dev, st, h = x.device, stream(), lib()
         E = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
-        # six slab reductions (4 split-K weight gradients + 2 LayerNorm dgamma/dbeta) are deferred and run as ONE launch
+        # the slab reductions (4 split-K weight gradients, 2 LayerNorm dgamma/dbeta, 1-2 LePE conv gradients) are deferred
+        # and run as ONE launch
         sizes = [h.cswin_linear_bwd_weight_workspace(M, C, Hd), h.cswin_linear_bwd_weight_workspace(M, Hd, C),
                  h.cswin_layernorm_bwd_workspace(M, C), h.cswin_linear_bwd_weight_workspace(M, C, C),
                  h.cswin_linear_bwd_weight_workspace(M, 3 * C, C), h.cswin_layernorm_bwd_workspace(M, C)]
         sizes = [(n + 255) // 256 * 256 for n in sizes]
         ws = _ws(sum(sizes), dev)
         wsp = [ctypes.c_void_p(ws.data_ptr() + sum(sizes[:i])) for i in range(6)]
-        jobs = (ReduceJob * 6)()
+        jobs = (ReduceJob * 8)()
         J = lambda i: ctypes.cast(ctypes.byref(jobs[i]), ctypes.c_void_p)
         # ---- MLP branch ----
         dpre = torch.empty_like(pre)
@@ -400,7 +401,7 @@ class _CSWinBlock(Function):
         naw = h.cswin_attn_bwd_workspace(B, reso, C, nb, ha, ia, split)
         aws = _ws(naw, dev)
         call("cswin_attn_bwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(lse), ptr(att), ptr(datt), ptr(dqkv),
-             _ptr_array(dlw), _ptr_array(dlb), ptr(aws), naw, B, reso, C, nb, ha, ia, split, scale, st)
+             _ptr_array(dlw), _ptr_array(dlb), ptr(aws), naw, B, reso, C, nb, ha, ia, split, scale, J(6), st)
         dwqkv = torch.empty_like(wqkv)
         dbqkv = E(3 * C) if has_qkv_bias else None
         call("cswin_linear_bwd_weight", ptr(dqkv), ptr(h1), None, 0, None, 1, ptr(dwqkv), ptr(dbqkv), wsp[4], sizes[4], M, 3 * C, C,
@@ -410,7 +411,7 @@ class _CSWinBlock(Function):
         dx, dg1, dbt1 = torch.empty_like(x), E(C), E(C)
         call("cswin_layernorm_bwd", ptr(dh1), ptr(x), ptr(m1), ptr(r1), ptr(g1), ptr(dx1), ptr(dx), ptr(dg1), ptr(dbt1), wsp[5],
              sizes[5], M, C, J(5), st)
-        call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), 6, st)
+        call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), 6 + nb, st)
         grads = (dx, None, None, None, None, None, None, None, None, None, dg1, dbt1, dwqkv, dbqkv, dwp, dbp, dg2, dbt2, dw1, db1,
                  dw2, db2)
         return grads + tuple(d.view(d.shape[0], 1, 3, 3) for d in dlw) + tuple(dlb)

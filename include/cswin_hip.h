@@ -61,11 +61,12 @@ int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* co
 size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split);
 /* autograd backward of the above: dqkv (B, L, 3C), dlepe_w[i] (Cb, 9), dlepe_b[i] (Cb) are overwritten.
  * y (the forward output) and lepe_b are only read for windows of more than 112 tokens (384x384 inputs), where a
- * two-pass path replaces the fused kernel; they may be NULL otherwise. */
+ * two-pass path replaces the fused kernel; they may be NULL otherwise.  The per-window partial slabs of the LePE conv
+ * weight / bias gradient are reduced by one extra launch, or left in deferred[0..nbranch) for cswin_rows_sum_multi. */
 int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, const float* lse,
                    const float* y, const float* dy, float* dqkv, float* const* dlepe_w, float* const* dlepe_b,
                    void* workspace, size_t ws_bytes, int B, int reso, int C, int nbranch, const int* heads, const int* idx,
-                   int split, float scale, void* stream);
+                   int split, float scale, cswin_reduce_job* deferred, void* stream);
 
 /* ---- img2windows / windows2img (cswin_unet.py:184-202): index-only, bit-exact ----
  * img (B, C, H, W) -> out (B*nH*nW, H_sp*W_sp, C);   win (B*nH*nW, H_sp*W_sp, C) -> out (B, H, W, C) */

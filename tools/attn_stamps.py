@@ -18,7 +18,7 @@ ia, ha = (ctypes.c_int * nb)(*idx), (ctypes.c_int * nb)(*hb)
 pa = lambda ts: (ctypes.c_void_p * nb)(*[t.data_ptr() for t in ts])
 nbytes = lib().cswin_attn_bwd_workspace(batch, reso, C, nb, ha, ia, split[si]); ws = torch.empty(nbytes // 4 + 4, device=dev)
 call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(lse), batch, reso, C, nb, ha, ia, split[si], 0.0, stream())
-def bwd(): call("cswin_attn_bwd", ptr(qkv), pa(w), pa(b), ptr(lse), ptr(y), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws), nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, stream())
+def bwd(): call("cswin_attn_bwd", ptr(qkv), pa(w), pa(b), ptr(lse), ptr(y), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws), nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, None, stream())
 for _ in range(3): bwd()
 torch.cuda.synchronize()
 st = torch.zeros(1 << 16, 8, dtype=torch.int64, device=dev)
@@ -26,8 +26,9 @@ h = lib(); h.cswin_debug_set_attn_stamps.argtypes = [ctypes.c_void_p]
 h.cswin_debug_set_attn_stamps(ctypes.c_void_p(st.data_ptr())); bwd(); torch.cuda.synchronize(); h.cswin_debug_set_attn_stamps(None)
 s = st.cpu().numpy(); s = s[s[:, 0] != 0]
 print(f"stage {si+1}: {len(s)} workgroups")
-names = ["P0 load->LDS", "P1 frags+lepe wgrad", "P2 loop1 (S,dP,delta)", "P3 loop2 (dV,dK,dS,dQ)", "barrier", "P4 dQ store"]
+names = ["load -> LDS", "loop1 (S, dP, delta)", "loop2 (dV, dK, dS)", "barrier + dQ", "LePE wgrad", "slab reduce + store"]
 for k, nm in enumerate(names):
     d = s[:, k + 1] - s[:, k]
-    print(f"  {nm:20s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f} cycles")
-d = s[:, 6] - s[:, 0]; print(f"  {'total':20s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f}")
+    print(f"  {nm:24s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f} shader cycles (s_memtime)")
+d = s[:, 6] - s[:, 0]; print(f"  {'total':24s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f}")
+d = s[:, 6].max() - s[:, 0].min(); print(f"  kernel span {d} cycles")
