@@ -98,6 +98,67 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ---- LePE taps ------------------------------------------------------------------------------------------------
+// The 3x3 depthwise conv is zero padded at the WINDOW border.  Reads use a clamped address and a select instead of a
+// branch, so that the LDS reads of all taps are in flight together.  THIN: the stripe is one token high or wide
+// (split_size 1, stage 1): only the three taps along the stripe can stay inside; they are picked with wave-uniform
+// arithmetic (tap j = (1, j) for a 1 x W stripe, (j, 1) for an H x 1 stripe) and the other six are never issued.
+// SIGN = +1: neighbour (r + ky - 1, c + kx - 1) (forward conv, weight gradient); -1: (r - ky + 1, c - kx + 1) (transpose).
+template <bool THIN, int SIGN>
+__device__ __forceinline__ f32x4 lepe_taps4(const AttnBranch& br, const float* __restrict__ src, const float* __restrict__ Wl,
+                                            int rr, int cc, int self_t, int d0, f32x4 acc) {
+    if constexpr (THIN) {
+        const bool row = br.H_sp == 1;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ky = row ? 1 : j, kx = row ? j : 1;
+            const int r2 = rr + SIGN * (ky - 1), c2 = cc + SIGN * (kx - 1);
+            const bool ok = (unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp;
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(&Wl[(ky * 3 + kx) * HD + d0]);
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(&src[(ok ? r2 * br.W_sp + c2 : self_t) * LDT + d0]);
+            acc += (ok ? 1.f : 0.f) * wv * vv;
+        }
+    } else {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int r2 = rr + SIGN * (ky - 1), c2 = cc + SIGN * (kx - 1);
+                const bool ok = (unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp;
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(&Wl[(ky * 3 + kx) * HD + d0]);
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(&src[(ok ? r2 * br.W_sp + c2 : self_t) * LDT + d0]);
+                acc += (ok ? 1.f : 0.f) * wv * vv;
+            }
+    }
+    return acc;
+}
+
+// weight-gradient accumulation of one token: a[tap] += g * V[neighbour(tap)][d]  (a[9] += g is done by the caller)
+template <bool THIN>
+__device__ __forceinline__ void lepe_wgrad_taps(const AttnBranch& br, const float* __restrict__ Vs, int rr, int cc, int t, int d,
+                                                float g, float* a) {
+    if constexpr (THIN) {
+        const bool row = br.H_sp == 1;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {                           // a[j] holds tap (1, j) or (j, 1); expanded by the caller
+            const int r2 = rr + (row ? 0 : j - 1), c2 = cc + (row ? j - 1 : 0);
+            const bool ok = (unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp;
+            const float vv = Vs[(ok ? r2 * br.W_sp + c2 : t) * LDT + d];
+            a[j] += ok ? g * vv : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int r2 = rr + ky - 1, c2 = cc + kx - 1;
+                const bool ok = (unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp;
+                const float vv = Vs[(ok ? r2 * br.W_sp + c2 : t) * LDT + d];
+                a[ky * 3 + kx] += ok ? g * vv : 0.f;
+            }
+    }
+}
+
 // =====================================================================================
 // forward
 // =====================================================================================
@@ -118,6 +179,7 @@ __global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnPa
     const int ch0 = br.c0 + w.g * p.hd;           // first channel of this head inside C
     const int N = w.N;
     const float* qkv_b = p.qkv + (long)w.b * L * C3;
+    const bool thin = br.H_sp == 1 || br.W_sp == 1;       // wave-uniform
 
     // this wave's first query tile: issue its Q loads first so their latency overlaps the K/V staging below
     f32x4 q0_pre = {0.f, 0.f, 0.f, 0.f}, q1_pre = q0_pre;
@@ -225,17 +287,7 @@ __global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnPa
             for (int df = 0; df < 2; ++df) {
                 const int d0 = 16 * df + 4 * kq;
                 f32x4 acc = *reinterpret_cast<const f32x4*>(&Wl[9 * HD + d0]);     // bias
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        // clamped address + select instead of a branch: all 9 taps' LDS reads are in flight together
-                        const int r2 = rr + ky - 1, c2 = cc + kx - 1;
-                        const bool ok = (unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp;
-                        const f32x4 wv = *reinterpret_cast<const f32x4*>(&Wl[(ky * 3 + kx) * HD + d0]);
-                        const f32x4 vv = *reinterpret_cast<const f32x4*>(&Vs[(ok ? r2 * br.W_sp + c2 : tq) * LDT + d0]);
-                        acc += (ok ? 1.f : 0.f) * wv * vv;
-                    }
+                acc = thin ? lepe_taps4<true, 1>(br, Vs, Wl, rr, cc, tq, d0, acc) : lepe_taps4<false, 1>(br, Vs, Wl, rr, cc, tq, d0, acc);
                 f32x4 out = o[df] * inv + acc;
                 if (d0 < p.hd) *reinterpret_cast<f32x4*>(p.y + ((long)w.b * L + lq) * p.C + ch0 + d0) = out;
             }
@@ -283,6 +335,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
     const float* dy_b = p.dy + (long)w.b * L * p.C;
     float* dqkv_b = p.dqkv + (long)w.b * L * C3;
     const float* lse_b = p.lse + ((long)w.b * p.heads_total + br.head0 + w.g) * L;
+    const bool thin = br.H_sp == 1 || br.W_sp == 1;       // wave-uniform
 
     ATTN_STAMP(0);
     for (int idx = tid; idx < NP * 8; idx += NTHREADS) {
@@ -381,17 +434,9 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
 #pragma unroll
         for (int df = 0; df < 2; ++df) {
             const int d0 = 16 * df + 4 * kq;
-            f32x4 acc = dVt[df];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int r2 = rr - ky + 1, c2 = cc - kx + 1;   // output position that read this key through tap (ky,kx)
-                    const bool ok = (unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp;
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(&Wl[(ky * 3 + kx) * HD + d0]);
-                    const f32x4 dv = *reinterpret_cast<const f32x4*>(&Ds[(ok ? r2 * br.W_sp + c2 : tk) * LDT + d0]);
-                    acc += (ok ? 1.f : 0.f) * wv * dv;
-                }
+            // output positions that read this key through tap (ky, kx): the transposed conv
+            const f32x4 acc = thin ? lepe_taps4<true, -1>(br, Ds, Wl, rr, cc, tk, d0, dVt[df])
+                                   : lepe_taps4<false, -1>(br, Ds, Wl, rr, cc, tk, d0, dVt[df]);
             if (d0 < p.hd) {
                 float* dst = dqkv_b + (long)lk * C3 + ch0 + d0;
                 *reinterpret_cast<f32x4*>(dst + p.C) = dKt[df] * p.scale;
@@ -437,16 +482,19 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
         for (int t = 2 * wave + (lane >> 5); t < N; t += 2 * NT) {
             const float g = Ds[t * LDT + d];
             const int rr = t / br.W_sp, cc = t - rr * br.W_sp;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int r2 = rr + ky - 1, c2 = cc + kx - 1;
-                    const bool ok = (unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp;
-                    const float vv = Vs[(ok ? r2 * br.W_sp + c2 : t) * LDT + d];
-                    a[ky * 3 + kx] += ok ? g * vv : 0.f;
-                }
+            if (thin) lepe_wgrad_taps<true>(br, Vs, rr, cc, t, d, g, a);
+            else lepe_wgrad_taps<false>(br, Vs, rr, cc, t, d, g, a);
             a[9] += g;
+        }
+        if (thin) {                                             // a[0..2] -> taps (1, j) or (j, 1); the other six are zero
+            const bool row = br.H_sp == 1;
+            const float t0 = a[0], t1 = a[1], t2 = a[2];
+            a[0] = a[2] = a[6] = a[8] = 0.f;
+            a[1] = row ? 0.f : t0;
+            a[3] = row ? t0 : 0.f;
+            a[4] = t1;
+            a[5] = row ? t2 : 0.f;
+            a[7] = row ? 0.f : t2;
         }
 #pragma unroll
         for (int i = 0; i < 10; ++i) {

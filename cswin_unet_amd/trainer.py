@@ -266,3 +266,100 @@ class DataParallelTrainer:
     def state_dict(self):
         """Reference checkpoint format: the model's state_dict (trainer.py:84)."""
         return self.model.state_dict()
+
+
+class _Prefetcher:
+    """Pinned host batches -> device on a side stream, one batch ahead of the step that consumes them."""
+
+    def __init__(self, loader, device):
+        self.it, self.device = iter(loader), device
+        self.stream = torch.cuda.Stream(device)
+        self._next()
+
+    def _next(self):
+        try:
+            batch = next(self.it)
+        except StopIteration:
+            self.batch = None
+            return
+        with torch.cuda.stream(self.stream):
+            self.batch = (batch['image'].to(self.device, non_blocking=True), batch['label'].to(self.device, non_blocking=True))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.batch is None:
+            raise StopIteration
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        img, lab = self.batch
+        img.record_stream(torch.cuda.current_stream(self.device))
+        lab.record_stream(torch.cuda.current_stream(self.device))
+        self._next()
+        return img, lab
+
+
+def trainer_synapse(args, model, snapshot_path, group=None, log_every=1):
+    """Counterpart of the reference's ``trainer_synapse(args, model, snapshot_path)`` (trainer.py:20-95) on the HIP engine.
+
+    args: root_path, list_dir, img_size, num_classes, batch_size (per GPU), base_lr, max_epochs, optionally num_workers.
+    Same dataset / augmentation / loss / optimiser / LR schedule / checkpoint schedule (``epoch_N.pth`` every third epoch
+    of the second half and at the end, :79-90).  Differences, all execution-side: one process per GPU (pass the process
+    group; each rank reads its own shard through a DistributedSampler) instead of nn.DataParallel; batches are prefetched
+    to the device on a side stream; the last incomplete batch of an epoch is dropped because the step is a captured
+    hipGraph with a fixed batch shape; tensorboard image logging is not reproduced."""
+    import logging
+    import random
+    import sys
+
+    import numpy as np
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+
+    from .checkpoint import save_checkpoint
+    from .datasets import RandomGenerator, Synapse_dataset
+
+    os.makedirs(snapshot_path, exist_ok=True)
+    logging.basicConfig(filename=os.path.join(snapshot_path, "log.txt"), level=logging.INFO,
+                        format='[%(asctime)s.%(msecs)03d] %(message)s', datefmt='%H:%M:%S')
+    if not any(isinstance(h, logging.StreamHandler) and getattr(h, "stream", None) is sys.stdout for h in logging.getLogger().handlers):
+        logging.getLogger().addHandler(logging.StreamHandler(sys.stdout))
+    logging.info(str(args))
+    rank = dist.get_rank(group) if group is not None else 0
+    world = dist.get_world_size(group) if group is not None else 1
+    device = next(model.parameters()).device
+    db_train = Synapse_dataset(base_dir=args.root_path, list_dir=args.list_dir, split="train",
+                               transform=RandomGenerator(output_size=[args.img_size, args.img_size]))
+    print("The length of train set is: {}".format(len(db_train)))
+    seed = getattr(args, "seed", 1234)
+
+    def worker_init_fn(worker_id):                                   # trainer.py:33-34
+        random.seed(seed + worker_id)
+        np.random.seed(seed + worker_id)
+
+    sampler = DistributedSampler(db_train, num_replicas=world, rank=rank, shuffle=True, seed=seed) if world > 1 else None
+    loader = DataLoader(db_train, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler,
+                        num_workers=getattr(args, "num_workers", 8), pin_memory=True, drop_last=True,
+                        worker_init_fn=worker_init_fn, persistent_workers=getattr(args, "num_workers", 8) > 0)
+    max_epoch = args.max_epochs
+    max_iterations = max_epoch * len(loader)
+    logging.info("{} iterations per epoch. {} max iterations ".format(len(loader), max_iterations))
+    model.train()
+    trainer = DataParallelTrainer(model, args.num_classes, base_lr=args.base_lr, max_iterations=max_iterations, group=group)
+    iter_num = 0
+    for epoch_num in range(max_epoch):
+        if sampler is not None:
+            sampler.set_epoch(epoch_num)
+        for image_batch, label_batch in _Prefetcher(loader, device):
+            stats = trainer.train_step(image_batch, label_batch)
+            iter_num += 1
+            if log_every and iter_num % log_every == 0 and rank == 0:
+                loss, loss_ce, _ = stats.tolist()                    # the only host sync of the loop
+                logging.info('iteration %d : loss : %f, loss_ce: %f' % (iter_num, loss, loss_ce))
+        save_interval = 3
+        last = epoch_num >= max_epoch - 1
+        if rank == 0 and (last or (epoch_num > int(max_epoch / 2) and (epoch_num + 1) % save_interval == 0)):
+            save_mode_path = os.path.join(snapshot_path, 'epoch_' + str(epoch_num) + '.pth')
+            save_checkpoint(model, save_mode_path)
+            logging.info("save model to {}".format(save_mode_path))
+    return "Training Finished!"

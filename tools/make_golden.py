@@ -263,14 +263,86 @@ def g5_model(ref):
     save("g7_model384", e)
 
 
+
+def _ns_config(ckpt=None):
+    """Plain-namespace stand-in for the yacs config (config.py + configs/cswin_tiny_224_lite.yaml values)."""
+    from types import SimpleNamespace as NS
+    return NS(DATA=NS(IMG_SIZE=224),
+              MODEL=NS(PRETRAIN_CKPT=ckpt, DROP_RATE=0.0, DROP_PATH_RATE=0.2,
+                       CSWIN=NS(PATCH_SIZE=4, IN_CHANS=3, EMBED_DIM=64, DEPTH=[1, 2, 9, 1], SPLIT_SIZE=[1, 2, 7, 7],
+                                NUM_HEADS=[2, 4, 8, 16], MLP_RATIO=4., QKV_BIAS=True, QK_SCALE=None)))
+
+
+def g8_checkpoint(ref):
+    """state_dict contract of the wrapper (vision_transformer.py:17-43) and the load_from remap (:45-72)."""
+    import json
+    import tempfile
+    from networks.vision_transformer import CSwinUnet
+    tmp = tempfile.mkdtemp()
+    cwd = os.getcwd()
+    os.chdir(tmp)                                     # the ctor writes cswin_unet.pth into the CWD (:36)
+    try:
+        net = CSwinUnet(_ns_config(), img_size=224, num_classes=9)
+        sd = net.state_dict()
+        contract = {k: list(v.shape) for k, v in sd.items()}
+        # a pretrained-style checkpoint: encoder tensors (closed form), one tensor of the wrong shape, one foreign key
+        enc = {k: v for k, v in net.cswin_unet.state_dict().items()
+               if k.startswith(("stage1.", "stage2.0.", "stage3.4.", "stage4.", "merge1.", "stage1_conv_embed."))}
+        ck = {k: T(det_normal("ckpt." + k, tuple(v.shape), 0.05)) for k, v in enc.items()}
+        ck["stage2.0.qkv.weight"] = torch.zeros(7, 5)                   # wrong shape -> dropped (for stage2 AND stage_up2)
+        ck["head.weight"] = torch.zeros(1000, 512)                       # not in the model -> ignored (strict=False)
+        path = os.path.join(tmp, "pre.pth")
+        torch.save({"state_dict_ema": ck}, path)
+        before = {k: v.clone() for k, v in net.cswin_unet.state_dict().items()}
+        net.load_from(_ns_config(path))
+        after = net.cswin_unet.state_dict()
+        changed = sorted(k for k in after if not torch.equal(after[k], before[k]))
+        sums = {k: float(after[k].double().abs().sum()) for k in changed}
+    finally:
+        os.chdir(cwd)
+    with open(os.path.join(OUT, "g8_checkpoint.json"), "w") as f:
+        json.dump({"state_dict": contract, "load_from_changed": changed, "load_from_abs_sums": sums,
+                   "ckpt_keys": sorted(ck)}, f, indent=0)
+    print(f"g8_checkpoint.json  {len(contract)} keys, {len(changed)} changed by load_from")
+
+
+def g9_augment(ref):
+    """RandomGenerator / random_rot_flip / random_rotate (datasets/dataset_synapse.py:12-47) on seeded inputs.
+    h5py and loguru (absent here, unused by these functions) are registered as empty modules for the import."""
+    import random
+    for name in ("h5py", "loguru"):
+        m = types.ModuleType(name)
+        m.logger = None
+        sys.modules.setdefault(name, m)
+    import importlib.util                      # by path: `datasets` on sys.path is the (unrelated) HuggingFace package
+    spec = importlib.util.spec_from_file_location("ref_dataset_synapse", os.path.join(REF, "datasets", "dataset_synapse.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    RandomGenerator = mod.RandomGenerator
+    d = {}
+    gen = RandomGenerator([224, 224])
+    for i in range(12):
+        size = (512, 512) if i % 3 else (224, 224)
+        img = det_normal(f"aug.img{i}", size).astype(np.float32) * 0.25 + 0.5
+        lab = det_labels(f"aug.lab{i}", (1,) + size, 9)[0].astype(np.float32)
+        # blocky labels so that order-0 rotation / zoom keeps structure
+        lab = np.kron(lab[:size[0] // 16, :size[1] // 16], np.ones((16, 16), np.float32))
+        random.seed(100 + i)
+        np.random.seed(200 + i)
+        out = gen({"image": img, "label": lab})
+        d[f"img{i}"] = out["image"].numpy()
+        d[f"lab{i}"] = out["label"].numpy().astype(np.uint8)
+    save("g9_augment", d)
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     _install_stubs()
     import networks.cswin_unet as ref
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
-    fns = {"g1": g1_index_maps, "g2": g2_attention, "g3": g3_blocks, "g4": g4_convs, "g5": g5_model}
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g8", "g9"]
+    fns = {"g1": g1_index_maps, "g2": g2_attention, "g3": g3_blocks, "g4": g4_convs, "g5": g5_model,
+           "g8": g8_checkpoint, "g9": g9_augment}
     cwd = os.getcwd()
     os.chdir("/tmp")
     try:
