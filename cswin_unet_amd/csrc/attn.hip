@@ -49,6 +49,8 @@ struct AttnParams {
     int hd;                // real head dim (8, 16, 24 or 32); LDS images and MFMA tiles are zero-padded to HD = 32
     float scale;
     int nbranch;
+    int ds_stride;         // fused backward: LDS row stride of the dS image (>= N, = 4 mod 8: conflict-free column writes)
+    int slab_rows;         // LePE gradient slab rows per window (fused backward: one per wave; two-pass path: 1)
     long long* stamps;     // debug (cswin_debug_set_attn_stamps): [workgroup][8] s_memtime stamps of wave 0, or NULL
     AttnBranch br[2];
 };
@@ -79,11 +81,11 @@ __device__ __forceinline__ int token_of(const AttnBranch& br, const WgInfo& w, i
 }
 
 // partial-slab row of workgroup (b, win, head g): element i = tap * HD + d of the [10][HD] scratch (tap 9 = bias)
-__device__ __forceinline__ void store_lepe_partial(const AttnParams& p, const AttnBranch& br, const WgInfo& w, int i, float v) {
+__device__ __forceinline__ void store_lepe_partial(const AttnParams& p, const AttnBranch& br, const WgInfo& w, int sub, int i, float v) {
     const int tap = i / HD, d = i - tap * HD;
     if (d >= p.hd) return;
     const int cb = br.heads * p.hd;                         // channels of this branch
-    float* row = br.dw_part + ((long)w.b * br.nWin + w.win) * (cb * 10);
+    float* row = br.dw_part + (((long)w.b * br.nWin + w.win) * p.slab_rows + sub) * (cb * 10);
     const int ch = w.g * p.hd + d;
     if (tap < 9) row[ch * 9 + tap] = v;
     else row[cb * 9 + ch] = v;
@@ -508,7 +510,276 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
         float sum = 0.f;
 #pragma unroll
         for (int k = 0; k < NT; ++k) sum += scratch[k * 10 * HD + i];
-        store_lepe_partial(p, br, w, i, sum);
+        store_lepe_partial(p, br, w, 0, i, sum);
+    }
+    ATTN_STAMP(6);
+}
+
+// sum over the 8 lanes that share lane >> 3 (quad swap, pair-of-quads swap, half-row mirror): pure VALU
+__device__ __forceinline__ float oct_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+    return v;
+}
+
+// Fused backward, windows of up to 112 tokens.  LDS: QK [NP][LDT] (Q, later K) | Ds [NP][LDT] (dO) | VS (V, later the
+// dS image [NP][ds_stride]) | lse, delta [NP] | LePE taps + bias [10][HD]: 79 KB for N = 98, two workgroups per CU.
+//   P0  q, v, dO -> LDS; the K / V fragments of this wave's 16 keys and the y chunks stay in registers
+//   P1  delta[q] = sum_d dO (y - LePE(v) - bias)  (= rowsum(P o dP), so P and dP never have to be held for a second pass);
+//       LePE weight / bias gradient partial of this wave -> global slab row (reduced by the caller's rows_sum launch)
+//   P2  per query tile: S, dP (MFMA) -> P, dS (VALU) -> dV^T += dO^T P, dK^T += Q^T dS (MFMA, the P / dS accumulator tiles
+//       are the B operands as they stand); dS -> LDS.  The S / dP products of tile qt + 1 are issued before the VALU
+//       work of tile qt.  Then dV += LePE^T(dO), dK, dV -> global.
+//   P3  K fragments -> LDS over the dead Q image; dQ^T = K^T dS^T per query tile (one per wave) -> global.
+template <int NT>
+__global__ __launch_bounds__(64 * NT, (NT <= 4 ? 4 : 2)) void attn_bwd2_kernel(AttnParams p) {
+    constexpr int NP = 16 * NT;
+    constexpr int NTHREADS = 64 * NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int S = p.ds_stride;
+    float* QK = smem;                       // [NP][LDT]
+    float* Ds = QK + NP * LDT;              // [NP][LDT]
+    float* VS = Ds + NP * LDT;              // V [NP][LDT], then dS [NP][S]
+    float* lse_s = VS + NP * (S > LDT ? S : LDT);
+    float* del_s = lse_s + NP;
+    float* Wl = del_s + NP;                 // [10][HD]
+
+    const WgInfo w = decode_wg(p, blockIdx.x);
+    const AttnBranch& br = p.br[w.bi];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int L = p.reso * p.reso, C3 = 3 * p.C;
+    const int ch0 = br.c0 + w.g * p.hd;
+    const int N = w.N;
+    const float* qkv_b = p.qkv + (long)w.b * L * C3;
+    const float* dy_b = p.dy + (long)w.b * L * p.C;
+    const float* y_b = p.y_in + (long)w.b * L * p.C;
+    float* dqkv_b = p.dqkv + (long)w.b * L * C3;
+    const float* lse_b = p.lse + ((long)w.b * p.heads_total + br.head0 + w.g) * L;
+    const bool thin = br.H_sp == 1 || br.W_sp == 1;       // wave-uniform
+
+    ATTN_STAMP(0);
+    // ---- P0: all global loads first, then the LDS stores ----
+    const int kw = wave;                               // key tile owned by this wave
+    const int tk = 16 * kw + li;                       // this lane's key token
+    const bool kvalid = tk < N;
+    const int lk = kvalid ? token_of(br, w, p.reso, tk) : 0;
+    f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0;
+    if (kvalid && 8 * kq < p.hd) {
+        const float* src = qkv_b + (long)lk * C3 + p.C + ch0 + 8 * kq;
+        k0 = *reinterpret_cast<const f32x4*>(src);
+        k1 = *reinterpret_cast<const f32x4*>(src + 4);
+    }
+    f32x4 qv[2], vv[2], dv[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * NTHREADS, row = idx >> 3, c4 = idx & 7;
+        qv[it] = vv[it] = dv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < N && 4 * c4 < p.hd) {
+            const int l = token_of(br, w, p.reso, row);
+            const float* src = qkv_b + (long)l * C3 + ch0 + 4 * c4;
+            qv[it] = *reinterpret_cast<const f32x4*>(src);
+            vv[it] = *reinterpret_cast<const f32x4*>(src + 2 * p.C);
+            dv[it] = *reinterpret_cast<const f32x4*>(dy_b + (long)l * p.C + ch0 + 4 * c4);
+        }
+    }
+    // P1 walks tokens t = 2 wave + half + 2 NT j (half-wave per token, lane & 31 = channel): its y values, loaded now
+    const int dch = lane & 31;
+    float yt[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int t = 2 * wave + (lane >> 5) + 2 * NT * j;
+        yt[j] = (t < N && dch < p.hd) ? y_b[(long)token_of(br, w, p.reso, t) * p.C + ch0 + dch] : 0.f;
+    }
+    for (int t = tid; t < NP; t += NTHREADS) {
+        lse_s[t] = t < N ? lse_b[token_of(br, w, p.reso, t)] : INFINITY;   // +inf -> P = 0 on padded query rows
+        del_s[t] = 0.f;
+    }
+    for (int i = tid; i < 10 * HD; i += NTHREADS) {
+        const int tap = i / HD, ch = i - tap * HD;
+        const int cb = ch0 - br.c0 + ch;
+        Wl[i] = ch >= p.hd ? 0.f : (tap < 9 ? br.lepe_w[cb * 9 + tap] : br.lepe_b[cb]);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * NTHREADS, row = idx >> 3, c4 = idx & 7;
+        *reinterpret_cast<f32x4*>(&QK[row * LDT + 4 * c4]) = qv[it];
+        *reinterpret_cast<f32x4*>(&VS[row * LDT + 4 * c4]) = vv[it];
+        *reinterpret_cast<f32x4*>(&Ds[row * LDT + 4 * c4]) = dv[it];
+    }
+    __syncthreads();
+    ATTN_STAMP(1);
+
+    // ---- P1: V fragment; per token: LePE weight-gradient terms, and delta = sum_d dO (y - bias - sum_tap W V_nbr) ----
+    float kf[8], vf[8];
+    {
+        const float* vp = &VS[tk * LDT + 8 * kq];
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp), v1 = *reinterpret_cast<const f32x4*>(vp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            kf[e] = k0[e];
+            kf[4 + e] = k1[e];
+            vf[e] = v0[e];
+            vf[4 + e] = v1[e];
+        }
+    }
+    float a[10];                                        // LePE gradient partial of this wave; stored at the very end so that
+    {                                                   // the barriers below do not wait for the global-store acknowledgements
+        float wt[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            a[i] = 0.f;
+            wt[i] = Wl[i * HD + dch];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = 2 * wave + (lane >> 5) + 2 * NT * j;
+            const bool tv = t < N;
+            const int tc = tv ? t : 0;
+            const float g = tv ? Ds[tc * LDT + dch] : 0.f;
+            const int rr = tc / br.W_sp, cc = tc - rr * br.W_sp;
+            float b[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) b[i] = 0.f;
+            if (thin) lepe_wgrad_taps<true>(br, VS, rr, cc, tc, dch, g, b);
+            else lepe_wgrad_taps<false>(br, VS, rr, cc, tc, dch, g, b);
+            float lw = 0.f;                             // g * sum_tap W[tap][d] V[nbr][d]
+            if (thin) {                                 // b[0..2] are taps (1, j) or (j, 1)
+                const bool row = br.H_sp == 1;
+                lw = (row ? wt[3] : wt[1]) * b[0] + wt[4] * b[1] + (row ? wt[5] : wt[7]) * b[2];
+                a[0] += b[0];
+                a[1] += b[1];
+                a[2] += b[2];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    lw += wt[i] * b[i];
+                    a[i] += b[i];
+                }
+            }
+            a[9] += g;
+            float part = g * (yt[j] - wt[9]) - lw;
+            part = row16_sum(part);
+            part += __shfl_xor(part, 16, 64);
+            if (tv && dch == 0) del_s[t] = part;
+        }
+        if (thin) {                                             // a[0..2] -> taps (1, j) or (j, 1); the other six are zero
+            const bool row = br.H_sp == 1;
+            const float t0 = a[0], t1 = a[1], t2 = a[2];
+            a[0] = a[2] = a[6] = a[8] = 0.f;
+            a[1] = row ? 0.f : t0;
+            a[3] = row ? t0 : 0.f;
+            a[4] = t1;
+            a[5] = row ? t2 : 0.f;
+            a[7] = row ? 0.f : t2;
+        }
+#pragma unroll
+        for (int i = 0; i < 10; ++i) a[i] += __shfl_xor(a[i], 32, 64);
+    }
+    ATTN_STAMP(2);
+    __syncthreads();                                    // V image dead: VS becomes the dS image; delta complete
+
+    // ---- P2: fused S / dP -> P, dS -> dV^T, dK^T ----
+    f32x4 dVt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 dKt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const bool colok = 16 * kw + li < S;               // dS columns beyond the stride would land in the next row
+    auto s_dp = [&](int qt, f32x4& sa, f32x4& da) {
+        const float* qp = &QK[(16 * qt + li) * LDT + 8 * kq];
+        const float* dp = &Ds[(16 * qt + li) * LDT + 8 * kq];
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(qp), q1 = *reinterpret_cast<const f32x4*>(qp + 4);
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(dp), d1 = *reinterpret_cast<const f32x4*>(dp + 4);
+        sa = da = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sa = mfma4(q0[e], kf[e], sa);               // S[q][key] = sum_d Q[q][d] K[key][d]
+            da = mfma4(d0[e], vf[e], da);               // dP[q][key] = sum_d dO[q][d] V[key][d]
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sa = mfma4(q1[e], kf[4 + e], sa);
+            da = mfma4(d1[e], vf[4 + e], da);
+        }
+    };
+    f32x4 sa, da;
+    s_dp(0, sa, da);
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+        f32x4 sn = sa, dn = da;
+        if (qt + 1 < NT) s_dp(qt + 1, sn, dn);
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_s[16 * qt + 4 * kq]);
+        const f32x4 de = *reinterpret_cast<const f32x4*>(&del_s[16 * qt + 4 * kq]);
+        f32x4 pr, ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pr[r] = kvalid ? __expf(sa[r] * p.scale - ls[r]) : 0.f;
+            ds[r] = pr[r] * (da[r] - de[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qrow = 16 * qt + 4 * kq + r;
+            const float* dop = &Ds[qrow * LDT + li];
+            const float* qp = &QK[qrow * LDT + li];
+            dVt[0] = mfma4(dop[0], pr[r], dVt[0]);
+            dVt[1] = mfma4(dop[16], pr[r], dVt[1]);
+            dKt[0] = mfma4(qp[0], ds[r], dKt[0]);
+            dKt[1] = mfma4(qp[16], ds[r], dKt[1]);
+            if (colok) VS[qrow * S + 16 * kw + li] = ds[r];
+        }
+        sa = sn;
+        da = dn;
+    }
+    // lane holds dV^T / dK^T [d = 16 df + 4 kq + e][key = tk]: add LePE^T(dO) to dV and store
+    if (kvalid) {
+        const int rr = tk / br.W_sp, cc = tk - rr * br.W_sp;
+#pragma unroll
+        for (int df = 0; df < 2; ++df) {
+            const int d0 = 16 * df + 4 * kq;
+            const f32x4 acc = thin ? lepe_taps4<true, -1>(br, Ds, Wl, rr, cc, tk, d0, dVt[df])
+                                   : lepe_taps4<false, -1>(br, Ds, Wl, rr, cc, tk, d0, dVt[df]);
+            if (d0 < p.hd) {
+                float* dst = dqkv_b + (long)lk * C3 + ch0 + d0;
+                *reinterpret_cast<f32x4*>(dst + p.C) = dKt[df] * p.scale;
+                *reinterpret_cast<f32x4*>(dst + 2 * p.C) = acc;
+            }
+        }
+    }
+    ATTN_STAMP(3);
+    __syncthreads();                                    // dS complete; Q image dead
+
+    // ---- P3: K image over Q, then dQ ----
+    {
+        float* kp = &QK[tk * LDT + 8 * kq];
+        *reinterpret_cast<f32x4*>(kp) = k0;
+        *reinterpret_cast<f32x4*>(kp + 4) = k1;
+    }
+    __syncthreads();
+    ATTN_STAMP(4);
+    {
+        const int qt = wave;
+        f32x4 dQt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            // columns beyond the stride read the head of the next row (finite) against K rows that are zero
+            const f32x4 ds = *reinterpret_cast<const f32x4*>(&VS[(16 * qt + li) * S + 16 * kt + 4 * kq]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* kp = &QK[(16 * kt + 4 * kq + r) * LDT + li];
+                dQt[0] = mfma4(kp[0], ds[r], dQt[0]);
+                dQt[1] = mfma4(kp[16], ds[r], dQt[1]);
+            }
+        }
+        const int tq = 16 * qt + li;
+        if (tq < N) {
+            float* dst = dqkv_b + (long)token_of(br, w, p.reso, tq) * C3 + ch0 + 4 * kq;
+            if (4 * kq < p.hd) *reinterpret_cast<f32x4*>(dst) = dQt[0] * p.scale;
+            if (16 + 4 * kq < p.hd) *reinterpret_cast<f32x4*>(dst + 16) = dQt[1] * p.scale;
+        }
+    }
+    ATTN_STAMP(5);
+    if (lane < 32) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) store_lepe_partial(p, br, w, wave, i * HD + lane, a[i]);
     }
     ATTN_STAMP(6);
 }
@@ -804,7 +1075,7 @@ __global__ __launch_bounds__(256) void lepe_wgrad_kernel(AttnParams p) {
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) s += scratch[k * 10 * HD + i];
-        store_lepe_partial(p, br, w, i, s);
+        store_lepe_partial(p, br, w, 0, i, s);
     }
 }
 
@@ -918,6 +1189,26 @@ int launch_bwd(const AttnParams& p, int nwg, hipStream_t st) {
     return CSWIN_OK;
 }
 
+inline int ds_stride_for(int N) {            // smallest stride >= N with stride = 4 (mod 8): 16-B aligned rows, and the four
+    int s = (N + 3) / 4 * 4;                 // row groups of a dS column write land in distinct banks
+    while (s % 8 != 4) s += 4;
+    return s;
+}
+
+template <int NT>
+int launch_bwd2(const AttnParams& p, int nwg, hipStream_t st) {
+    const int NP = 16 * NT, S = p.ds_stride;
+    const size_t lds = (size_t)(2 * NP * LDT + NP * (S > LDT ? S : LDT) + 2 * NP + 10 * HD) * sizeof(float);
+    static size_t reserved = 0;         // one-time per size: not a stream operation, keep it out of graph captures
+    if (lds > 64 * 1024 && lds > reserved) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd2_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { cswin_set_error("attn_bwd: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return CSWIN_ERR_HIP; }
+        reserved = lds;
+    }
+    hipLaunchKernelGGL((attn_bwd2_kernel<NT>), dim3(nwg), dim3(64 * NT), lds, st, p);
+    return CSWIN_OK;
+}
+
 long long* g_attn_stamps = nullptr;     // debug only (cswin_debug_set_attn_stamps)
 
 }  // namespace
@@ -954,12 +1245,15 @@ int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* co
     return CSWIN_OK;
 }
 
+// LePE gradient slab rows per window: one per wave of the fused kernel, 1 on the two-pass path
+static int slab_rows_for(int nt) { return nt > 7 ? 1 : (nt <= 4 ? 4 : (nt <= 6 ? 6 : 7)); }
+
 size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split) {
     AttnParams p = {};
     int nt, nwg;
     if (fill_params(p, "attn_bwd_workspace", B, reso, C, nbranch, heads, idx, split, 0.f, &nt, &nwg)) return 0;
-    // LePE partial slabs + delta (B, heads, L) (used by the two-pass path)
-    size_t n = (size_t)nwg * 10 * HD;
+    // LePE partial slabs (7 rows per window covers every path) + delta (B, heads, L) (used by the two-pass path)
+    size_t n = (size_t)nwg * 10 * HD * 7;
     n += (size_t)B * p.heads_total * reso * reso;
     return n * sizeof(float);
 }
@@ -975,20 +1269,23 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
     if (rc) return rc;
     CSWIN_REQUIRE(qkv && lse && dy && dqkv && lepe_w && dlepe_w && dlepe_b, CSWIN_ERR_SHAPE, "attn_bwd: null pointer");
     CSWIN_REQUIRE(workspace && ws_bytes >= cswin_attn_bwd_workspace(B, reso, C, nbranch, heads, idx, split), CSWIN_ERR_WORKSPACE, "attn_bwd: workspace too small");
+    CSWIN_REQUIRE(y && lepe_b, CSWIN_ERR_SHAPE, "attn_bwd: the forward output y and lepe_b are required");
+    static const bool force_two_pass = getenv("CSWIN_ATTN_BWD_TWO_PASS") != nullptr;     // tuning aid
+    const bool two_pass = nt > 7 || force_two_pass;
+    p.slab_rows = two_pass ? 1 : slab_rows_for(nt);
+    p.ds_stride = ds_stride_for(p.br[0].H_sp * p.br[0].W_sp);
     for (int i = 0; i < nbranch; ++i) {
         p.br[i].lepe_w = lepe_w[i];
-        p.br[i].lepe_b = lepe_b ? lepe_b[i] : nullptr;
-        p.br[i].dw_part = (float*)workspace + (size_t)p.br[i].wg_begin * 10 * HD;
+        p.br[i].lepe_b = lepe_b[i];
+        p.br[i].dw_part = (float*)workspace + (size_t)p.br[i].wg_begin * 10 * HD * p.slab_rows;
     }
     p.stamps = g_attn_stamps;
     p.y_in = y;
-    p.delta = (float*)workspace + (size_t)nwg * 10 * HD;
+    p.delta = (float*)workspace + (size_t)nwg * 10 * HD * 7;
     p.qkv = qkv; p.lse = const_cast<float*>(lse); p.dy = dy; p.dqkv = dqkv;
     hipStream_t st = (hipStream_t)stream;
-    static const bool force_two_pass = getenv("CSWIN_ATTN_BWD_TWO_PASS") != nullptr;     // tuning aid
-    if (nt > 7 || force_two_pass) {
-        // windows of more than 112 tokens (384x384: N = 144, 288): two-pass path, needs the forward output and the LePE bias
-        CSWIN_REQUIRE(y && lepe_b, CSWIN_ERR_SHAPE, "attn_bwd: windows of %d tokens need y and lepe_b (large-window path)", p.br[0].H_sp * p.br[0].W_sp);
+    if (two_pass) {
+        // windows of more than 112 tokens (384x384: N = 144, 288): two-pass path
         const int N = p.br[0].H_sp * p.br[0].W_sp, nblk = (N + 63) / 64;
         const long items = (long)B * p.heads_total * reso * reso;
         hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items * 8 + 255) / 256)), dim3(256), 0, st, p);
@@ -997,10 +1294,25 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
         hipLaunchKernelGGL(lepe_wgrad_kernel, dim3(nwg), dim3(256), 0, st, p);
         rc = CSWIN_OK;
     } else {
-        switch (nt) {
-            case 1: case 2: case 3: case 4: rc = launch_bwd<4>(p, nwg, st); break;
-            case 5: case 6: rc = launch_bwd<6>(p, nwg, st); break;
-            default: rc = launch_bwd<7>(p, nwg, st); break;
+        // Two fused kernels.  attn_bwd_kernel (Q, K, V, dO and an N x N dS image in LDS, one workgroup per CU at N = 98)
+        // is the faster one for windows of up to 64 tokens; attn_bwd2_kernel (79 KB at N = 98: two workgroups per CU,
+        // delta from the saved output so that S / dP / dV / dK are one loop) wins from 65 tokens up (measured, B = 24).
+        static const char* force = getenv("CSWIN_ATTN_BWD_KERNEL");                      // tuning aid: "1" or "2"
+        const bool v1 = force ? force[0] == '1' : nt <= 4;
+        if (v1) {
+            p.slab_rows = 1;
+            for (int i = 0; i < nbranch; ++i) p.br[i].dw_part = (float*)workspace + (size_t)p.br[i].wg_begin * 10 * HD;
+            switch (nt) {
+                case 1: case 2: case 3: case 4: rc = launch_bwd<4>(p, nwg, st); break;
+                case 5: case 6: rc = launch_bwd<6>(p, nwg, st); break;
+                default: rc = launch_bwd<7>(p, nwg, st); break;
+            }
+        } else {
+            switch (nt) {
+                case 1: case 2: case 3: case 4: rc = launch_bwd2<4>(p, nwg, st); break;
+                case 5: case 6: rc = launch_bwd2<6>(p, nwg, st); break;
+                default: rc = launch_bwd2<7>(p, nwg, st); break;
+            }
         }
     }
     if (rc) return rc;
@@ -1011,7 +1323,7 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
     for (int i = 0; i < nbranch; ++i) {
         const AttnBranch& br = p.br[i];
         const long cb = (long)br.heads * p.hd;
-        cswin_reduce_job job = {br.dw_part, dlepe_w[i], dlepe_b[i], cb * 9, cb * 10, cb * 10, B * br.nWin, 0};
+        cswin_reduce_job job = {br.dw_part, dlepe_w[i], dlepe_b[i], cb * 9, cb * 10, cb * 10, B * br.nWin * p.slab_rows, 0};
         if (deferred) {
             deferred[i] = job;
             continue;
