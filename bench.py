@@ -150,6 +150,10 @@ def main():
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=24)
+    ap.add_argument("--matmul", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32: exact fp32 MFMA (BASELINE configs[1], the default and the headline); bf16: Linear/conv operands "
+                         "rounded to bf16 in LDS, bf16 MFMA, fp32 accumulate and storage (configs[2..4])")
+    ap.add_argument("--img-size", type=int, default=None, help="override DATA.IMG_SIZE (384 uses split [1,2,12,12])")
     args = ap.parse_args()
 
     from cswin_unet_amd.config import get_config
@@ -160,7 +164,14 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path)"
     dev = torch.device("cuda", torch.cuda.current_device())
-    config = get_config(args.cfg)
+    over = {}
+    if args.img_size:
+        over["DATA.IMG_SIZE"] = args.img_size
+        if args.img_size == 384:
+            over["MODEL.CSWIN.SPLIT_SIZE"] = [1, 2, 12, 12]           # the yaml split does not divide 24
+    config = get_config(args.cfg, **over)
+    import cswin_unet_amd
+    cswin_unet_amd.set_matmul_precision(args.matmul)
     num_classes = 9
     torch.manual_seed(1234)
     model = CSwinUnet(config, img_size=config.DATA.IMG_SIZE, num_classes=num_classes).to(dev)
@@ -199,13 +210,14 @@ def main():
         out = {"metric": "training images/sec (224x224, cswin_tiny)", "value": round(world * args.batch * args.steps / elapsed, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "cswin_tiny_224_lite, synthetic 224x224 9-class, bs=24/GPU, fp32, "
+               "dtype": "f32" if args.matmul == "fp32" else "bf16 GEMM operands, f32 accumulate/storage", "data": "synthetic",
+               "config": {"workload": f"{os.path.splitext(os.path.basename(args.cfg))[0]}, synthetic {config.DATA.IMG_SIZE}x{config.DATA.IMG_SIZE} 9-class, "
+                                      f"bs={args.batch}/GPU, {args.matmul} matmul, "
                                       "fwd + 0.4CE+0.6Dice + bwd + SGD(momentum) step, drop_path 0.2",
                           "global_batch": world * args.batch, "img_size": config.DATA.IMG_SIZE,
                           "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
                "final_loss": {"loss": round(loss[0], 5), "ce": round(loss[1], 5), "dice": round(loss[2], 5)},
-               "model_tflops": round(33.2e9 * world * args.batch * args.steps / elapsed / 1e12, 2)}
+               "model_tflops": round(33.2e9 * world * args.batch * args.steps / elapsed / 1e12, 2) if config.DATA.IMG_SIZE == 224 and config.MODEL.CSWIN.EMBED_DIM == 64 else None}
         if world == 1 and not args.skip_roofline:
             log("[bench] attention roofline sub-benchmark ...")
             out["roofline"] = attention_roofline(args.batch, config.MODEL.CSWIN, config.DATA.IMG_SIZE)

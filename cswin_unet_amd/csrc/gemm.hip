@@ -26,6 +26,14 @@ namespace {
 
 constexpr int BKMAX = 64;     // largest reduction tile (split sizes are multiples of it)
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// matmul precision of the whole family (cswin_set_matmul_precision): 0 = exact fp32 MFMA (default, the parity path);
+// 1 = operands rounded to bf16 while they are staged into LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulation and fp32
+// storage everywhere (BASELINE configs 3-5 name bf16; this is the GEMM-input half of that)
+int g_matmul_precision = 0;
+
 // ------------------------------------------------------------------------------------
 // operand sources: a logical matrix S(i, j) whose fast (contiguous) index is j
 // ------------------------------------------------------------------------------------
@@ -278,7 +286,7 @@ __device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[FM
 // [g*BK/KW, (g+1)*BK/KW) of every tile, the groups' accumulators are summed through LDS at the end).  When M*N is too
 // small to give every SIMD >= 2 independent MFMA chains (stage-3/4 shapes with long K) this doubles / quadruples the
 // resident waves per workgroup without a global split-K reduction.
-template <int BM, int BN, int BK, int KW, bool A_RC, bool B_RC, int VEC, int EPI, bool SCALE_A, class ASrc, class BSrc>
+template <int BM, int BN, int BK, int KW, bool A_RC, bool B_RC, int VEC, int EPI, bool SCALE_A, int PREC, class ASrc, class BSrc>
 __global__ __launch_bounds__(256 * KW) void gemm_kernel(ASrc A, BSrc B, Epilogue epi, int M, int N, int R,
                                                     int r_per_split, int tiles_m, int tiles_n) {
     constexpr int WM = BM / 2, WN = BN / 2;          // 4 waves as 2 x 2
@@ -292,6 +300,11 @@ __global__ __launch_bounds__(256 * KW) void gemm_kernel(ASrc A, BSrc B, Epilogue
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     float* As = lds;
     float* Bs = lds + A_ELEMS;
+    // PREC == 1: both operands as [row][r] bf16 images (r-contiguous: one ds_read_b128 = the 8 k-values of a lane)
+    constexpr int LD16 = BK + 8;                     // in bf16 elements: 16-B aligned rows, 36-dword stride at BK = 64
+    unsigned short* As16 = reinterpret_cast<unsigned short*>(lds);
+    unsigned short* Bs16 = As16 + BM * LD16;
+    static_assert(PREC == 0 || ((BM + BN) * LD16 * 2 <= LDS_FLOATS * 4 && (BK / KW) % 16 == 0), "bf16 tile does not fit");
 
     constexpr int NTH = 256 * KW;
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, kg = tid >> 8;
@@ -390,11 +403,32 @@ __global__ __launch_bounds__(256 * KW) void gemm_kernel(ASrc A, BSrc B, Epilogue
         for (int q = 0; q < QA; ++q) {
             f32x4 v = pa[q];
             if (SCALE_A) v *= pas[q];
-            *reinterpret_cast<f32x4*>(&As[(a_r + q * A_RPP) * LDA + 4 * a_c]) = v;
+            if constexpr (PREC == 1) {
+                if (A_RC) {
+                    *reinterpret_cast<bf16x4*>(&As16[(a_r + q * A_RPP) * LD16 + 4 * a_c]) = __builtin_convertvector(v, bf16x4);
+                } else {                                 // source is row(m)-contiguous: transpose into the [m][r] image
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        As16[(4 * a_c + e) * LD16 + a_r + q * A_RPP] = __builtin_bit_cast(unsigned short, (__bf16)v[e]);
+                }
+            } else {
+                *reinterpret_cast<f32x4*>(&As[(a_r + q * A_RPP) * LDA + 4 * a_c]) = v;
+            }
         }
 #pragma unroll
-        for (int q = 0; q < QB; ++q)
-            *reinterpret_cast<f32x4*>(&Bs[(b_r + q * B_RPP) * LDB + 4 * b_c]) = pb[q];
+        for (int q = 0; q < QB; ++q) {
+            if constexpr (PREC == 1) {
+                if (B_RC) {
+                    *reinterpret_cast<bf16x4*>(&Bs16[(b_r + q * B_RPP) * LD16 + 4 * b_c]) = __builtin_convertvector(pb[q], bf16x4);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        Bs16[(4 * b_c + e) * LD16 + b_r + q * B_RPP] = __builtin_bit_cast(unsigned short, (__bf16)pb[q][e]);
+                }
+            } else {
+                *reinterpret_cast<f32x4*>(&Bs[(b_r + q * B_RPP) * LDB + 4 * b_c]) = pb[q];
+            }
+        }
     };
 
     f32x16 acc[FM][FN];
@@ -418,9 +452,32 @@ __global__ __launch_bounds__(256 * KW) void gemm_kernel(ASrc A, BSrc B, Epilogue
             const bool more = r0 + BK < r_end;
             if (more) fetch(r0 + BK);
             if (do_colsum) {
+                if constexpr (PREC == 1) {
 #pragma unroll 8
-                for (int r = 0; r < BK; ++r) csum += As[r * LDA + tid];
+                    for (int r = 0; r < BK; ++r)
+                        csum += __builtin_bit_cast(float, (unsigned)As16[tid * LD16 + r] << 16);
+                } else {
+#pragma unroll 8
+                    for (int r = 0; r < BK; ++r) csum += As[r * LDA + tid];
+                }
             }
+            if constexpr (PREC == 1) {
+#pragma unroll
+                for (int kk = kg * (BK / KW); kk < (kg + 1) * (BK / KW); kk += 16) {
+                    bf16x8 af[FM], bf[FN];
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+                        af[i] = *reinterpret_cast<const bf16x8*>(&As16[(wm0 + i * 32 + li) * LD16 + kk + 8 * lh]);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        bf[j] = *reinterpret_cast<const bf16x8*>(&Bs16[(wn0 + j * 32 + li) * LD16 + kk + 8 * lh]);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                }
+            } else
 #pragma unroll
             for (int kk = kg * (BK / KW); kk < (kg + 1) * (BK / KW); kk += 8) {
                 f32x4 af[FM], bf[FN];
@@ -495,13 +552,13 @@ __global__ __launch_bounds__(256 * KW) void gemm_kernel(ASrc A, BSrc B, Epilogue
     if (do_colsum && m0 + tid < M) epi.colsum[(long)split * epi.colsum_stride + m0 + tid] = csum;
 }
 
-template <int BM, int BN, int BK, int KW, bool A_RC, bool B_RC, int VEC, int EPI, bool SCALE_A, class ASrc, class BSrc>
+template <int BM, int BN, int BK, int KW, bool A_RC, bool B_RC, int VEC, int EPI, bool SCALE_A, int PREC, class ASrc, class BSrc>
 void launch_cfg(const ASrc& A, const BSrc& B, const Epilogue& epi, int M, int N, int R, int splits, int r_per_split,
                 hipStream_t st) {
     int tm = cdiv(M, BM), tn = cdiv(N, BN);
     dim3 grid(tm * tn * splits);
     static const int pad_lds = getenv("CSWIN_GEMM_PAD_LDS") ? atoi(getenv("CSWIN_GEMM_PAD_LDS")) : 0;   // tuning aid: caps residency
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, KW, A_RC, B_RC, VEC, EPI, SCALE_A, ASrc, BSrc>), grid, dim3(256 * KW), pad_lds, st, A, B, epi,
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, KW, A_RC, B_RC, VEC, EPI, SCALE_A, PREC, ASrc, BSrc>), grid, dim3(256 * KW), pad_lds, st, A, B, epi,
                        M, N, R, r_per_split, tm, tn);
 }
 
@@ -523,12 +580,9 @@ void launch_gemm(const ASrc& A, const BSrc& B, const Epilogue& epi_in, int M, in
     epi.vec_store = epilogue_vec_ok(epi, N);
     auto blocks = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(N, bn) * splits; };
     auto waste = [&](int bn) { return (double)cdiv(N, bn) * bn / N; };
-    static const int forced = getenv("CSWIN_GEMM_TILE") ? atoi(getenv("CSWIN_GEMM_TILE")) : 0;   // tuning aid
     static const long want = getenv("CSWIN_GEMM_WANT") ? atol(getenv("CSWIN_GEMM_WANT")) : 384;
     (void)waste; (void)want;
     static const int forced_kw = getenv("CSWIN_GEMM_KW") ? atoi(getenv("CSWIN_GEMM_KW")) : 0;                    // tuning aid
-    if (forced == 1) return launch_cfg<128, 128, 32, 1, A_RC, B_RC, VEC, EPI, SCALE_A>(A, B, epi, M, N, R, splits, r_per_split, st);
-    if (forced == 2) return launch_cfg<128, 64, 32, 1, A_RC, B_RC, VEC, EPI, SCALE_A>(A, B, epi, M, N, R, splits, r_per_split, st);
     // 64x64 tiles everywhere (measured best, profiles/round1_gemm_bench.txt).  With fewer than ~2 workgroups per CU and a long
     // reduction, split the k-range of each tile over 2 or 4 wave groups so every SIMD still has independent MFMA chains.
     const long nb = blocks(64, 64);
@@ -538,9 +592,16 @@ void launch_gemm(const ASrc& A, const BSrc& B, const Epilogue& epi_in, int M, in
     if (nb < 320 && r_len >= 512) kw = 4;
     if (!A_RC && !B_RC && r_len >= 256 && kw < 2) kw = 2;      // weight gradients: measured 5-8 % faster
     if (forced_kw) kw = forced_kw;
-    if (kw == 4) launch_cfg<64, 64, 64, 4, A_RC, B_RC, VEC, EPI, SCALE_A>(A, B, epi, M, N, R, splits, r_per_split, st);
-    else if (kw == 2) launch_cfg<64, 64, 64, 2, A_RC, B_RC, VEC, EPI, SCALE_A>(A, B, epi, M, N, R, splits, r_per_split, st);
-    else launch_cfg<64, 64, 32, 1, A_RC, B_RC, VEC, EPI, SCALE_A>(A, B, epi, M, N, R, splits, r_per_split, st);
+    if (g_matmul_precision == 1) {
+        // bf16 operands: 16x fewer MFMA cycles per tile, the kernel is bound by staging and barriers: one k-tile of 64,
+        // and two wave groups only where a long reduction meets few workgroups
+        if (kw >= 2) launch_cfg<64, 64, 64, 2, A_RC, B_RC, VEC, EPI, SCALE_A, 1>(A, B, epi, M, N, R, splits, r_per_split, st);
+        else launch_cfg<64, 64, 64, 1, A_RC, B_RC, VEC, EPI, SCALE_A, 1>(A, B, epi, M, N, R, splits, r_per_split, st);
+        return;
+    }
+    if (kw == 4) launch_cfg<64, 64, 64, 4, A_RC, B_RC, VEC, EPI, SCALE_A, 0>(A, B, epi, M, N, R, splits, r_per_split, st);
+    else if (kw == 2) launch_cfg<64, 64, 64, 2, A_RC, B_RC, VEC, EPI, SCALE_A, 0>(A, B, epi, M, N, R, splits, r_per_split, st);
+    else launch_cfg<64, 64, 32, 1, A_RC, B_RC, VEC, EPI, SCALE_A, 0>(A, B, epi, M, N, R, splits, r_per_split, st);
 }
 
 long long* g_stamps = nullptr;     // debug only (cswin_debug_set_stamps)
@@ -571,6 +632,16 @@ void choose_split(int M, int out_rows, int out_cols, int* splits, int* r_per_spl
 // C ABI
 // ======================================================================================
 extern "C" {
+
+// 0: exact fp32 MFMA (default); 1: bf16 operands, fp32 accumulate (Linear and conv entry points).  Returns the previous mode,
+// or a negative error code for an unknown mode.  Process-wide: set it between steps, not concurrently with launches.
+int cswin_set_matmul_precision(int mode) {
+    CSWIN_REQUIRE(mode == 0 || mode == 1, CSWIN_ERR_UNSUPPORTED, "set_matmul_precision: mode %d (0 = fp32, 1 = bf16 operands)", mode);
+    const int prev = g_matmul_precision;
+    g_matmul_precision = mode;
+    return prev;
+}
+int cswin_get_matmul_precision(void) { return g_matmul_precision; }
 
 // debug aid (not part of include/cswin_hip.h): device buffer [nblk][4] of int64 that GEMM workgroups stamp with s_memtime
 void cswin_debug_set_stamps(void* p) { g_stamps = (long long*)p; }

@@ -46,6 +46,12 @@ typedef struct cswin_reduce_job {
 const char* cswin_last_error(void);
 int cswin_abi_version(void);
 int cswin_device_ok(void); /* 1 if the current HIP device is gfx950 */
+/* Matmul precision of the Linear and convolution entry points: 0 = exact fp32 MFMA (default; the parity path of BASELINE
+ * configs[1]); 1 = operands rounded to bf16 while staged into LDS, bf16 MFMA, fp32 accumulation, fp32 tensors in HBM (the
+ * "bf16" of BASELINE configs[2..4] as far as the GEMMs go; torch.autocast(bfloat16) on the reference's Linear / Conv2d is the
+ * closest reference-side equivalent).  Process-wide; returns the previous mode or a negative error code. */
+int cswin_set_matmul_precision(int mode);
+int cswin_get_matmul_precision(void);
 
 /* ---- LePEAttention (cswin_unet.py:31-109), both branches of a CSWinBlock in one launch (:171-176) ----
  * qkv (B, L, 3C) = output of the qkv Linear, channel layout [q | k | v] (:169).

@@ -582,3 +582,68 @@ def test_trainer_synapse_on_synthetic_dataset(N, tmp_path):
     msg = load_checkpoint(other, str(ck))
     assert not msg.missing_keys and not msg.unexpected_keys
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bf16-operand matmul mode (BASELINE configs[2..4] name bf16).  Same fp32 oracle, looser STATED bound: operands are rounded
+# to 8 mantissa bits (relative 2^-9 each), products accumulate in fp32; observed max|diff|/rms is ~5e-3 per GEMM.
+# ---------------------------------------------------------------------------------------------------------------------
+BF16_RTOL = 3e-2
+
+
+@pytest.fixture()
+def bf16_matmul():
+    import cswin_unet_amd
+    prev = cswin_unet_amd.set_matmul_precision("bf16")
+    yield
+    cswin_unet_amd.set_matmul_precision(prev)
+
+
+def _rel(got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    return float((got - ref).abs().max()) / (float(ref.pow(2).mean().sqrt()) + 1e-30)
+
+
+@pytest.mark.parametrize("M,Nn,K", [(4704, 768, 256), (1176, 512, 2048), (3000, 64, 64), (777, 130, 100)])
+def test_linear_bf16_operands(ops, bf16_matmul, M, Nn, K):
+    x, w, b = det_normal("lb.x", (M, K)), det_normal("lb.w", (Nn, K), 1 / np.sqrt(K)), det_normal("lb.b", (Nn,), 0.1)
+    dy = det_normal("lb.dy", (M, Nn))
+    xr, wr, br = (torch.from_numpy(a).requires_grad_() for a in (x, w, b))
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr.backward(torch.from_numpy(dy))
+    xd, wd, bd = T(x, True), T(w, True), T(b, True)
+    yd = ops.linear(xd, wd, bd)
+    yd.backward(T(dy))
+    errs = {"y": _rel(yd, yr), "dx": _rel(xd.grad, xr.grad), "dw": _rel(wd.grad, wr.grad), "db": _rel(bd.grad, br.grad)}
+    with open(LOG, "a") as f:
+        f.write(f"linear_bf16 M{M} N{Nn} K{K}: {errs}\n")
+    assert all(np.isfinite(e) and e < BF16_RTOL for e in errs.values()), errs
+    assert errs["y"] > 1e-5          # the bf16 path really ran (fp32 MFMA would be ~1e-6)
+
+
+def test_model_bf16_operands_training_step(N, ops, golden, bf16_matmul):
+    """Whole model, one step, bf16 GEMM / conv operands against the fp32 reference outputs (g5).  The rounding of ~60 chained
+    contractions accumulates: observed max|diff|/rms is 7.3e-2 on the logits and 1.2e-1 .. 2.7e-1 on parameter gradients; the
+    bounds below are those observations x 1.5 - 2 (stated, as SURVEY 8c asks for the bf16 configs), the loss is within 2 %."""
+    g = golden("g5_model")
+    net = _golden_model(N).train()
+    x = T(det_normal("model.x", (2, 1, 224, 224))).repeat(1, 3, 1, 1)
+    lab = T(det_labels("model.labels", (2, 224, 224), 9))
+    logits = net(x)
+
+    def packed_err(t, prefix):
+        a = t.detach().float().cpu().numpy().reshape(-1)
+        ref, stride = g[prefix + "vals"], int(g[prefix + "stride"])
+        rms = float(np.sqrt(float(g[prefix + "sqsum"]) / a.size)) + 1e-30
+        err = float(np.abs(a[::stride] - ref).max()) / rms
+        with open(LOG, "a") as f:
+            f.write(f"model_bf16.{prefix} {err:.3e}\n")
+        return err
+
+    e = packed_err(logits, "logits.")
+    assert 1e-4 < e < 0.15, e
+    loss, stats = ops.ce_dice_loss(logits, lab)
+    assert abs(float(loss) - float(g["loss"])) < 2e-2 * abs(float(g["loss"]))
+    loss.backward()
+    params = dict(net.named_parameters())
+    for n in ["stage3.4.qkv.weight", "merge2.conv.weight", "upsample1.encoder.weight", "output.weight", "concat_linear3.weight"]:
+        assert packed_err(params[n].grad, f"grad.{n}.") < 0.4, n
