@@ -616,12 +616,17 @@ Epilogue plain_epilogue(float* C, long ldc) {
 
 // split count for the M-reduction of a weight gradient: enough workgroups to fill the chip
 void choose_split(int M, int out_rows, int out_cols, int* splits, int* r_per_split) {
+    // Every workgroup is resident at once and the kernel ends with the most loaded CU, so aim at a workgroup count
+    // that is a whole multiple of the 256 CUs (3 per CU): slices need not be multiples of the k-tile (the loaders mask
+    // the ragged last tile), only of 8.
+    static const int target = getenv("CSWIN_GEMM_SPLIT_WGS") ? atoi(getenv("CSWIN_GEMM_SPLIT_WGS")) : 768;   // tuning aid
     long tiles = (long)cdiv(out_rows, 64) * cdiv(out_cols, 64);
-    int s = (int)((768 + tiles - 1) / tiles);
+    int s = (int)(target / tiles);
+    if (s < 1) s = 1;
     int max_s = cdiv(M, 2 * BKMAX);
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
-    int rps = cdiv(cdiv(M, s), BKMAX) * BKMAX;
+    int rps = cdiv(cdiv(M, s), 8) * 8;
     *splits = cdiv(M, rps);
     *r_per_split = rps;
 }

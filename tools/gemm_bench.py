@@ -20,6 +20,8 @@ def timed(fn, reps=20, rounds=5):
     return best
 
 B = int(os.environ.get("BATCH", "24"))
+import cswin_unet_amd
+cswin_unet_amd.set_matmul_precision(os.environ.get("MATMUL", "fp32"))      # MATMUL=bf16: bf16 operands (streaming-bound proxy)
 shapes = []
 for si, (L, C) in enumerate([(3136, 64), (784, 128), (196, 256), (49, 512)]):
     M = B * L
@@ -39,6 +41,7 @@ for name, M, N, K in shapes:
     fl = 2.0 * M * N * K
     c = counts[name[:2]]
     tot["fwd"] += c * tf; tot["dx"] += c * tdx; tot["dw"] += c * tdw; flops += 3 * c * fl
-    print(f"{name:8s} M={M:6d} N={N:5d} K={K:5d}  fwd {tf*1e6:7.1f}us {fl/tf/1e12:6.1f}TF | dx {tdx*1e6:7.1f}us {fl/tdx/1e12:6.1f}TF | dw {tdw*1e6:7.1f}us {fl/tdw/1e12:6.1f}TF")
+    by = 4.0 * (M * K + N * K + M * N)        # minimal bytes of one pass (each operand once)
+    print(f"{name:8s} M={M:6d} N={N:5d} K={K:5d}  fwd {tf*1e6:7.1f}us {fl/tf/1e12:6.1f}TF {by/tf/1e12:4.2f}TB/s | dx {tdx*1e6:7.1f}us {fl/tdx/1e12:6.1f}TF {by/tdx/1e12:4.2f}TB/s | dw {tdw*1e6:7.1f}us {fl/tdw/1e12:6.1f}TF {by/tdw/1e12:4.2f}TB/s")
 s = sum(tot.values())
 print("per-step totals (ms):", {k: round(v * 1e3, 3) for k, v in tot.items()}, "sum", round(s * 1e3, 3), f"-> {flops/s/1e12:.1f} TF/s over {flops/1e9:.0f} GFLOP")

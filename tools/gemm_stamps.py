@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""In-kernel timeline of one GEMM launch: gemm_stamps.py M N K mode(fwd|dx)"""
+"""In-kernel timeline of one GEMM launch: gemm_stamps.py M N K mode(fwd|dx|dw)  [MATMUL=bf16]"""
 import os, sys, ctypes
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,9 +8,14 @@ M, N, K = (int(a) for a in sys.argv[1:4]); mode = sys.argv[4]
 x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda"); b = torch.randn(N, device="cuda")
 dy = torch.randn(M, N, device="cuda"); y = torch.empty(M, N, device="cuda"); dx = torch.empty(M, K, device="cuda")
 st = torch.zeros(65536, 8, dtype=torch.int64, device="cuda")
+import cswin_unet_amd
+cswin_unet_amd.set_matmul_precision(os.environ.get("MATMUL", "fp32"))
+dw = torch.empty(N, K, device="cuda"); db = torch.empty(N, device="cuda")
+nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K); ws = torch.empty(nbytes // 4 + 4, device="cuda")
 h = lib(); h.cswin_debug_set_stamps.argtypes = [ctypes.c_void_p]
 def run():
     if mode == "fwd": call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, stream())
+    elif mode == "dw": call("cswin_linear_bwd_weight", ptr(dy), ptr(x), None, 0, None, 1, ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, None, stream())
     else: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, stream())
 for _ in range(3): run()
 torch.cuda.synchronize()
