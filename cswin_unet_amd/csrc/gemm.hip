@@ -287,16 +287,20 @@ __device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[FM
 // small to give every SIMD >= 2 independent MFMA chains (stage-3/4 shapes with long K) this doubles / quadruples the
 // resident waves per workgroup without a global split-K reduction.
 template <int BM, int BN, int BK, int KW, bool A_RC, bool B_RC, int VEC, int EPI, bool SCALE_A, int PREC, class ASrc, class BSrc>
-__global__ __launch_bounds__(256 * KW) void gemm_kernel(ASrc A, BSrc B, Epilogue epi, int M, int N, int R,
+__global__ __launch_bounds__(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KW) void gemm_kernel(ASrc A, BSrc B, Epilogue epi, int M, int N, int R,
                                                     int r_per_split, int tiles_m, int tiles_n) {
-    constexpr int WM = BM / 2, WN = BN / 2;          // 4 waves as 2 x 2
+    // waves of one k-group: 2 x 2 for 64 x 64 (and larger) tiles, 2 x 1 for 64 x 32: the narrow tile
+    // exists for launches whose 64 x 64 tile count is a poor multiple of the 256 CUs (every workgroup is resident at once,
+    // so the kernel ends with the most loaded CU)
+    constexpr int WGM = BM >= 64 ? 2 : 1, WGN = BN >= 64 ? 2 : 1, NW = WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int FM = WM / 32, FN = WN / 32;        // 32x32 fragments per wave
     constexpr int LDR = BK + 4;                      // [row][r] image: 16-B padded rows -> conflict-free b128 reads
     constexpr int LDA = A_RC ? LDR : BM + 4;
     constexpr int LDB = B_RC ? LDR : BN + 4;
     constexpr int A_ELEMS = A_RC ? BM * LDR : BK * (BM + 4);
     constexpr int B_ELEMS = B_RC ? BN * LDR : BK * (BN + 4);
-    constexpr int LDS_FLOATS = (A_ELEMS + B_ELEMS) > 4 * EP_WAVE_FLOATS ? (A_ELEMS + B_ELEMS) : 4 * EP_WAVE_FLOATS;
+    constexpr int LDS_FLOATS = (A_ELEMS + B_ELEMS) > NW * EP_WAVE_FLOATS ? (A_ELEMS + B_ELEMS) : NW * EP_WAVE_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     float* As = lds;
     float* Bs = lds + A_ELEMS;
@@ -306,8 +310,8 @@ __global__ __launch_bounds__(256 * KW) void gemm_kernel(ASrc A, BSrc B, Epilogue
     unsigned short* Bs16 = As16 + BM * LD16;
     static_assert(PREC == 0 || ((BM + BN) * LD16 * 2 <= LDS_FLOATS * 4 && (BK / KW) % 16 == 0), "bf16 tile does not fit");
 
-    constexpr int NTH = 256 * KW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, kg = tid >> 8;
+    constexpr int NTH = 64 * NW * KW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % NW, kg = tid / (64 * NW);
     const int li = lane & 31, lh = lane >> 5;
     // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so give every XCD a
     // CONTIGUOUS range of logical blocks, ordered [split][m-tile][n-tile]: the blocks that re-read one A row panel
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256 * KW) void gemm_kernel(ASrc A, BSrc B, Epilogue
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const int r_begin = split * r_per_split;
     const int r_end = min(R, r_begin + r_per_split);
-    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
 
     // loader geometry
     constexpr int QA = BM * BK / (4 * NTH), QB = BN * BK / (4 * NTH); // chunks (16 B) per thread per tile
@@ -518,12 +522,12 @@ __global__ __launch_bounds__(256 * KW) void gemm_kernel(ASrc A, BSrc B, Epilogue
     if (epi.stamps && tid == 0) epi.stamps[8L * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
     if (KW > 1) {
         // sum the wave groups' accumulators (native C/D layout, lane-contiguous LDS patches, binary tree)
-        static_assert(KW == 1 || (KW / 2) * 4 * FM * FN * 16 * 64 <= LDS_FLOATS, "LDS too small for the k-group reduction");
+        static_assert(KW == 1 || (KW / 2) * NW * FM * FN * 16 * 64 <= LDS_FLOATS, "LDS too small for the k-group reduction");
         constexpr int PATCH = FM * FN * 16 * 64;
 #pragma unroll
         for (int half = KW / 2; half >= 1; half >>= 1) {
             if (kg >= half && kg < 2 * half) {
-                float* dst = lds + ((kg - half) * 4 + wave) * PATCH + lane;
+                float* dst = lds + ((kg - half) * NW + wave) * PATCH + lane;
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(256 * KW) void gemm_kernel(ASrc A, BSrc B, Epilogue
             }
             __syncthreads();
             if (kg < half) {
-                const float* src = lds + (kg * 4 + wave) * PATCH + lane;
+                const float* src = lds + (kg * NW + wave) * PATCH + lane;
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -558,7 +562,7 @@ void launch_cfg(const ASrc& A, const BSrc& B, const Epilogue& epi, int M, int N,
     int tm = cdiv(M, BM), tn = cdiv(N, BN);
     dim3 grid(tm * tn * splits);
     static const int pad_lds = getenv("CSWIN_GEMM_PAD_LDS") ? atoi(getenv("CSWIN_GEMM_PAD_LDS")) : 0;   // tuning aid: caps residency
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, KW, A_RC, B_RC, VEC, EPI, SCALE_A, PREC, ASrc, BSrc>), grid, dim3(256 * KW), pad_lds, st, A, B, epi,
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, KW, A_RC, B_RC, VEC, EPI, SCALE_A, PREC, ASrc, BSrc>), grid, dim3(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KW), pad_lds, st, A, B, epi,
                        M, N, R, r_per_split, tm, tn);
 }
 
@@ -583,22 +587,41 @@ void launch_gemm(const ASrc& A, const BSrc& B, const Epilogue& epi_in, int M, in
     static const long want = getenv("CSWIN_GEMM_WANT") ? atol(getenv("CSWIN_GEMM_WANT")) : 384;
     (void)waste; (void)want;
     static const int forced_kw = getenv("CSWIN_GEMM_KW") ? atoi(getenv("CSWIN_GEMM_KW")) : 0;                    // tuning aid
-    // 64x64 tiles everywhere (measured best, profiles/round1_gemm_bench.txt).  With fewer than ~2 workgroups per CU and a long
-    // reduction, split the k-range of each tile over 2 or 4 wave groups so every SIMD still has independent MFMA chains.
-    const long nb = blocks(64, 64);
+    // Tile choice.  64 x 64 is the most efficient tile (profiles/round1_gemm_bench.txt), but every workgroup of these
+    // launches is resident at once and the kernel ends with the most loaded CU: with t tiles the critical CU does
+    // ceil(t / 256) of them.  When that is a poor multiple (stage 3: 296 tiles -> 2 where 1.16 would do) a smaller tile
+    // shortens the critical path although it is a little less efficient per flop (penalties measured with gemm_bench).
+    static const int forced_tile = getenv("CSWIN_GEMM_TILE") ? atoi(getenv("CSWIN_GEMM_TILE")) : 0;  // tuning aid: 1 = 64x64, 2 = 64x32
+    // measured (profiles/round1_gemm_tiles.txt): a 64 x 32 tile costs ~1.2x per flop, so it only pays where it cuts the
+    // critical CU's share by more than that (296 -> 592 tiles: 2 -> 1.5 units); 32 x 32 single-wave tiles never paid.
+    static const double pen2 = getenv("CSWIN_GEMM_PEN2") ? atof(getenv("CSWIN_GEMM_PEN2")) : 1.20;
+    auto cost = [&](int bm, int bn, double pen) { return (double)((blocks(bm, bn) + 255) / 256) * bm * bn * pen; };
+    int tile = 1;
+    if (splits == 1 && cost(64, 32, pen2) < cost(64, 64, 1.0)) tile = 2;
+    if (forced_tile) tile = forced_tile;
     const int r_len = r_per_split < R ? r_per_split : R;
+    if (g_matmul_precision == 1) {
+        // bf16 operands: 16x fewer MFMA cycles per tile, the kernel is bound by staging and barriers: one k-tile of 64,
+        // and two wave groups only where a long reduction meets few workgroups
+        const long nb = blocks(64, 64);
+        if ((nb < 640 && r_len >= 256) || (!A_RC && !B_RC && r_len >= 256))
+            launch_cfg<64, 64, 64, 2, A_RC, B_RC, VEC, EPI, SCALE_A, 1>(A, B, epi, M, N, R, splits, r_per_split, st);
+        else launch_cfg<64, 64, 64, 1, A_RC, B_RC, VEC, EPI, SCALE_A, 1>(A, B, epi, M, N, R, splits, r_per_split, st);
+        return;
+    }
+    if (tile == 2) {
+        if (blocks(64, 32) < 640 && r_len >= 256)
+            return launch_cfg<64, 32, 64, 2, A_RC, B_RC, VEC, EPI, SCALE_A, 0>(A, B, epi, M, N, R, splits, r_per_split, st);
+        return launch_cfg<64, 32, 32, 1, A_RC, B_RC, VEC, EPI, SCALE_A, 0>(A, B, epi, M, N, R, splits, r_per_split, st);
+    }
+    // 64 x 64: with fewer than ~2 workgroups per CU and a long reduction, split the k-range of each tile over 2 or 4 wave
+    // groups so every SIMD still has independent MFMA chains.
+    const long nb = blocks(64, 64);
     int kw = 1;
     if (nb < 640 && r_len >= 256) kw = 2;
     if (nb < 320 && r_len >= 512) kw = 4;
     if (!A_RC && !B_RC && r_len >= 256 && kw < 2) kw = 2;      // weight gradients: measured 5-8 % faster
     if (forced_kw) kw = forced_kw;
-    if (g_matmul_precision == 1) {
-        // bf16 operands: 16x fewer MFMA cycles per tile, the kernel is bound by staging and barriers: one k-tile of 64,
-        // and two wave groups only where a long reduction meets few workgroups
-        if (kw >= 2) launch_cfg<64, 64, 64, 2, A_RC, B_RC, VEC, EPI, SCALE_A, 1>(A, B, epi, M, N, R, splits, r_per_split, st);
-        else launch_cfg<64, 64, 64, 1, A_RC, B_RC, VEC, EPI, SCALE_A, 1>(A, B, epi, M, N, R, splits, r_per_split, st);
-        return;
-    }
     if (kw == 4) launch_cfg<64, 64, 64, 4, A_RC, B_RC, VEC, EPI, SCALE_A, 0>(A, B, epi, M, N, R, splits, r_per_split, st);
     else if (kw == 2) launch_cfg<64, 64, 64, 2, A_RC, B_RC, VEC, EPI, SCALE_A, 0>(A, B, epi, M, N, R, splits, r_per_split, st);
     else launch_cfg<64, 64, 32, 1, A_RC, B_RC, VEC, EPI, SCALE_A, 0>(A, B, epi, M, N, R, splits, r_per_split, st);
