@@ -50,7 +50,7 @@ struct AttnParams {
     float scale;
     int nbranch;
     int ds_stride;         // fused backward: LDS row stride of the dS image (>= N, = 4 mod 8: conflict-free column writes)
-    int slab_rows;         // LePE gradient slab rows per window (fused backward: one per wave; two-pass path: 1)
+    int slab_rows;         // LePE gradient slab rows per window (1 on every current path)
     long long* stamps;     // debug (cswin_debug_set_attn_stamps): [workgroup][8] s_memtime stamps of wave 0, or NULL
     AttnBranch br[2];
 };
@@ -527,7 +527,7 @@ __device__ __forceinline__ float oct_sum(float v) {
 // dS image [NP][ds_stride]) | lse, delta [NP] | LePE taps + bias [10][HD]: 79 KB for N = 98, two workgroups per CU.
 //   P0  q, v, dO -> LDS; the K / V fragments of this wave's 16 keys and the y chunks stay in registers
 //   P1  delta[q] = sum_d dO (y - LePE(v) - bias)  (= rowsum(P o dP), so P and dP never have to be held for a second pass);
-//       LePE weight / bias gradient partial of this wave -> global slab row (reduced by the caller's rows_sum launch)
+//       LePE weight / bias gradient partial of this wave (kept in registers; combined over the waves at the very end)
 //   P2  per query tile: S, dP (MFMA) -> P, dS (VALU) -> dV^T += dO^T P, dK^T += Q^T dS (MFMA, the P / dS accumulator tiles
 //       are the B operands as they stand); dS -> LDS.  The S / dP products of tile qt + 1 are issued before the VALU
 //       work of tile qt.  Then dV += LePE^T(dO), dK, dV -> global.
@@ -624,8 +624,8 @@ __global__ __launch_bounds__(64 * NT, (NT <= 4 ? 4 : 2)) void attn_bwd2_kernel(A
             vf[4 + e] = v1[e];
         }
     }
-    float a[10];                                        // LePE gradient partial of this wave; stored at the very end so that
-    {                                                   // the barriers below do not wait for the global-store acknowledgements
+    float a[10];                                        // LePE gradient partial of this wave; reduced and stored at the very end
+    {                                                   // so that the barriers below do not wait for global-store acknowledgements
         float wt[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
@@ -777,9 +777,18 @@ __global__ __launch_bounds__(64 * NT, (NT <= 4 ? 4 : 2)) void attn_bwd2_kernel(A
         }
     }
     ATTN_STAMP(5);
+    // LePE gradient partials of the NT waves -> one slab row per workgroup, through the (now dead) K image
+    __syncthreads();
     if (lane < 32) {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) store_lepe_partial(p, br, w, wave, i * HD + lane, a[i]);
+        for (int i = 0; i < 10; ++i) QK[(wave * 10 + i) * HD + lane] = a[i];
+    }
+    __syncthreads();
+    for (int i = tid; i < 10 * HD; i += NTHREADS) {
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) sum += QK[k * 10 * HD + i];
+        store_lepe_partial(p, br, w, 0, i, sum);
     }
     ATTN_STAMP(6);
 }
@@ -1245,15 +1254,12 @@ int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* co
     return CSWIN_OK;
 }
 
-// LePE gradient slab rows per window: one per wave of the fused kernel, 1 on the two-pass path
-static int slab_rows_for(int nt) { return nt > 7 ? 1 : (nt <= 4 ? 4 : (nt <= 6 ? 6 : 7)); }
-
 size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split) {
     AttnParams p = {};
     int nt, nwg;
     if (fill_params(p, "attn_bwd_workspace", B, reso, C, nbranch, heads, idx, split, 0.f, &nt, &nwg)) return 0;
-    // LePE partial slabs (7 rows per window covers every path) + delta (B, heads, L) (used by the two-pass path)
-    size_t n = (size_t)nwg * 10 * HD * 7;
+    // LePE partial slabs + delta (B, heads, L) (used by the two-pass path)
+    size_t n = (size_t)nwg * 10 * HD;
     n += (size_t)B * p.heads_total * reso * reso;
     return n * sizeof(float);
 }
@@ -1272,16 +1278,16 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
     CSWIN_REQUIRE(y && lepe_b, CSWIN_ERR_SHAPE, "attn_bwd: the forward output y and lepe_b are required");
     static const bool force_two_pass = getenv("CSWIN_ATTN_BWD_TWO_PASS") != nullptr;     // tuning aid
     const bool two_pass = nt > 7 || force_two_pass;
-    p.slab_rows = two_pass ? 1 : slab_rows_for(nt);
+    p.slab_rows = 1;
     p.ds_stride = ds_stride_for(p.br[0].H_sp * p.br[0].W_sp);
     for (int i = 0; i < nbranch; ++i) {
         p.br[i].lepe_w = lepe_w[i];
         p.br[i].lepe_b = lepe_b[i];
-        p.br[i].dw_part = (float*)workspace + (size_t)p.br[i].wg_begin * 10 * HD * p.slab_rows;
+        p.br[i].dw_part = (float*)workspace + (size_t)p.br[i].wg_begin * 10 * HD;
     }
     p.stamps = g_attn_stamps;
     p.y_in = y;
-    p.delta = (float*)workspace + (size_t)nwg * 10 * HD * 7;
+    p.delta = (float*)workspace + (size_t)nwg * 10 * HD;
     p.qkv = qkv; p.lse = const_cast<float*>(lse); p.dy = dy; p.dqkv = dqkv;
     hipStream_t st = (hipStream_t)stream;
     if (two_pass) {
@@ -1300,8 +1306,6 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
         static const char* force = getenv("CSWIN_ATTN_BWD_KERNEL");                      // tuning aid: "1" or "2"
         const bool v1 = force ? force[0] == '1' : nt <= 4;
         if (v1) {
-            p.slab_rows = 1;
-            for (int i = 0; i < nbranch; ++i) p.br[i].dw_part = (float*)workspace + (size_t)p.br[i].wg_begin * 10 * HD;
             switch (nt) {
                 case 1: case 2: case 3: case 4: rc = launch_bwd<4>(p, nwg, st); break;
                 case 5: case 6: rc = launch_bwd<6>(p, nwg, st); break;

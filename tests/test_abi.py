@@ -56,8 +56,8 @@ def test_workspace_queries_are_host_only():
     assert h.cswin_layernorm_bwd_workspace(4704, 256) > 0
     assert h.cswin_linear_bwd_weight_workspace(4704, 768, 256) >= 768 * 256 * 4
     heads, idx = (ctypes.c_int * 2)(4, 4), (ctypes.c_int * 2)(0, 1)
-    # LePE gradient slabs (up to 7 rows of [10][32] per (branch, window, head)) + delta (B, heads, L)
-    assert h.cswin_attn_bwd_workspace(24, 14, 256, 2, heads, idx, 7) == (24 * 2 * 4 * 2 * 320 * 7 + 24 * 8 * 196) * 4
+    # LePE gradient slabs (one [10][32] per (branch, window, head)) + delta (B, heads, L)
+    assert h.cswin_attn_bwd_workspace(24, 14, 256, 2, heads, idx, 7) == (24 * 2 * 4 * 2 * 320 + 24 * 8 * 196) * 4
     assert h.cswin_loss_workspace(24, 9, 224 * 224) > 0
     bad = (ctypes.c_int * 1)(3)
     one = (ctypes.c_int * 1)(16)
