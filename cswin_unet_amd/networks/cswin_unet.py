@@ -304,6 +304,12 @@ class CSWinTransformer(nn.Module):
         self.x1 = x
         x = self._run(self.stage2, self.merge1(x))
         self.x2 = x
+        self.enc_mid_in = None
+        if getattr(self, "detach_decoder_inputs", False) and torch.is_grad_enabled():
+            # second cut of the trainer's phased backward (see forward()): merge2 onwards consumes a detached leaf, so
+            # stage4..merge2 and stage2..patch-embed are separate autograd graphs with contiguous parameter ranges
+            x = x.detach().requires_grad_()
+            self.enc_mid_in = x
         x = self._run(self.stage3, self.merge2(x))
         self.x3 = x
         x = self._run(self.stage4, self.merge3(x))

@@ -11,9 +11,11 @@ the execution model, MI355X-first:
     is the reference's, not a per-rank Dice.
   * gradients are packed by one multi-tensor launch into a flat buffer which is all-reduced in a few large buckets
     (sized for 7 point-to-point xGMI links, not for many small NVSwitch messages) and consumed by one fused SGD launch.
-  * the step is captured into three hipGraphs (forward + loss sums | loss + decoder backward + packing | encoder backward
-    + packing) with the collectives between them, so ~1000 kernel launches cost three graph launches on the host and the
-    decoder half of the gradient all-reduce overlaps the encoder half of the backward pass.
+  * the step is captured into four hipGraphs (forward + loss sums | loss + decoder backward + packing | encoder backward
+    merge2..norm + packing | encoder backward patch-embed..stage2 + packing) with the collectives between them, so ~700
+    kernel launches cost four graph launches on the host, the decoder's gradient all-reduce overlaps the encoder backward,
+    the deep encoder's (stage 3/4: 92 % of the encoder bytes) overlaps the shallow encoder backward, and only the last
+    ~2.7 MB bucket is exposed.
 
 The protocol (which collectives, which scalings) lives in ``DataParallelTrainer`` and is device agnostic; the device work
 lives in an *engine*.  ``HipEngine`` is the product (C ABI kernels, hipGraphs).  tests/test_dp_gloo.py drives the same
@@ -80,6 +82,8 @@ class HipEngine:
         self.n_enc = is_dec.index(True) if True in is_dec else len(names)
         self.split_backward = 0 < self.n_enc < len(names) and all(is_dec[self.n_enc:]) and hasattr(self.core, "forward_features")
         self.core.detach_decoder_inputs = self.split_backward
+        # second cut inside the encoder, in front of merge2: parameters [n_mid, n_enc) = merge2, stage3, merge3, stage4, norm
+        self.n_mid = next(i for i, n in enumerate(names) if "merge2" in n.split(".")[:2]) if self.split_backward else 0
         dev = self.opt.flat_param.device
         self.sums = torch.zeros(1 + 3 * num_classes, dtype=torch.float32, device=dev)
         self.stats = torch.zeros(3, dtype=torch.float32, device=dev)          # [loss, ce, dice] of the last step
@@ -135,18 +139,33 @@ class HipEngine:
         self.opt.gather_grads(n_enc, len(params))
         return [core.xb, core.x1, core.x2, core.x3], list(grads[len(params) - n_enc:])
 
-    def _backward_encoder(self, boundary):
-        bound, dbound = boundary
-        params, n_enc = self.opt.params, self.n_enc
-        grads = torch.autograd.grad(bound, params[:n_enc], dbound)
-        for p, g in zip(params[:n_enc], grads):
+    def _backward_encoder_deep(self, boundary):
+        """merge2 .. norm (92 % of the encoder's parameters): from the bottleneck and the stage-3 skip back to the
+        detached stage-2 output.  Returns what the shallow phase needs."""
+        (xb, x1, x2, x3), (dxb, dx1, dx2, dx3) = boundary
+        params, lo, hi = self.opt.params, self.n_mid, self.n_enc
+        mid = self.core.enc_mid_in
+        grads = torch.autograd.grad([xb, x3], params[lo:hi] + [mid], [dxb, dx3])
+        for p, g in zip(params[lo:hi], grads):
             p.grad = g
-        self.opt.gather_grads(0, n_enc)
+        self.opt.gather_grads(lo, hi)
+        return [x2, x1], [dx2 + grads[-1], dx1]
+
+    def _backward_encoder(self, boundary, lo=0, hi=None):
+        bound, dbound = boundary
+        params = self.opt.params
+        hi = self.n_enc if hi is None else hi
+        grads = torch.autograd.grad(bound, params[lo:hi], dbound)
+        for p, g in zip(params[lo:hi], grads):
+            p.grad = g
+        self.opt.gather_grads(lo, hi)
 
     def _phase_ranges(self):
         n = len(self.opt.params)
         if not self.split_backward:
             return [self.opt.flat_range(0, n)]
+        if self.n_mid:
+            return [self.opt.flat_range(self.n_enc, n), self.opt.flat_range(self.n_mid, self.n_enc), self.opt.flat_range(0, self.n_mid)]
         return [self.opt.flat_range(self.n_enc, n), self.opt.flat_range(0, self.n_enc)]
 
     def _capture(self, img, lab, dice_grad_scale):
@@ -160,7 +179,7 @@ class HipEngine:
                 self.finalize(lab.numel())
                 boundary = self._backward_decoder(logits, lab, dice_grad_scale)
                 if boundary is not None:
-                    self._backward_encoder(boundary)
+                    self._run_encoder_phases(boundary)
         torch.cuda.current_stream().wait_stream(side)
         self._img, self._lab = img.clone(), lab.clone()
         self.opt.zero_grad()
@@ -171,10 +190,29 @@ class HipEngine:
         with torch.cuda.graph(graphs[1], pool=graphs[0].pool()):
             boundary = self._backward_decoder(logits, self._lab, dice_grad_scale)
         if boundary is not None:
-            graphs.append(torch.cuda.CUDAGraph())
-            with torch.cuda.graph(graphs[2], pool=graphs[0].pool()):
-                self._backward_encoder(boundary)
+            for phase in self._encoder_phases(boundary):
+                graphs.append(torch.cuda.CUDAGraph())
+                with torch.cuda.graph(graphs[-1], pool=graphs[0].pool()):
+                    phase()
         self._graphs = graphs
+
+    def _encoder_phases(self, boundary):
+        """The encoder half as callables, one per all-reduce bucket boundary (deep part first: it owns 92 % of the bytes)."""
+        if not self.n_mid:
+            return [lambda: self._backward_encoder(boundary)]
+        state = {}
+
+        def deep():
+            state["shallow"] = self._backward_encoder_deep(boundary)
+
+        def shallow():
+            self._backward_encoder(state["shallow"], 0, self.n_mid)
+
+        return [deep, shallow]
+
+    def _run_encoder_phases(self, boundary):
+        for phase in self._encoder_phases(boundary):
+            phase()
 
     # ---- protocol hooks -----------------------------------------------------------------------------------------
     def forward_sums(self, img, lab, dice_grad_scale):
@@ -206,8 +244,9 @@ class HipEngine:
             boundary = self._backward_decoder(self._logits, self._lab_eager, dice_grad_scale)
             yield ranges[0]
             if boundary is not None:
-                self._backward_encoder(boundary)
-                yield ranges[1]
+                for phase, r in zip(self._encoder_phases(boundary), ranges[1:]):
+                    phase()
+                    yield r
             self._logits = None
 
     def apply(self, grad_scale):
@@ -254,7 +293,7 @@ class DataParallelTrainer:
                 # the work enqueued so far) while the next backward phase computes.  Few large buckets: xGMI is 7
                 # point-to-point links, per-message latency matters more than on a switched fabric.
                 g = eng.flat_grad
-                step = max((hi - lo + self.nbuckets - 1) // self.nbuckets, 1)
+                step = max((hi - lo + self.nbuckets - 1) // self.nbuckets, 1 << 22)      # never below 16 MB per message
                 works += [dist.all_reduce(g[o:min(o + step, hi)], group=self.group, async_op=True) for o in range(lo, hi, step)]
         for w in works:
             w.wait()
