@@ -178,7 +178,8 @@ def main():
     model.train()
     total_steps = args.warmup + args.steps + 8
     trainer = DataParallelTrainer(model, num_classes, base_lr=0.05, max_iterations=max(total_steps, 1000), group=group,
-                                  use_graph=not args.no_graph)
+                                  use_graph=not args.no_graph,
+                                  allreduce_dtype=torch.bfloat16 if args.matmul == "bf16" else None)
     img, lab = synthetic_batch(args.batch, config.DATA.IMG_SIZE, num_classes, 1234 + rank, dev)
 
     log(f"[bench] rank {rank}/{world}: model built, capturing ...")

@@ -80,7 +80,7 @@ class OracleEngine:
         self.flat_param.sub_(self.lr * self.flat_mom)
 
 
-def _run(rank, world, port, out):
+def _run(rank, world, port, out, wire_dtype=None):
     from cswin_unet_amd.trainer import DataParallelTrainer
     group = None
     if world > 1:
@@ -91,7 +91,8 @@ def _run(rank, world, port, out):
     lab = torch.from_numpy(det_labels("dp.lab", (2, 64, 64), CFG["num_classes"]))
     if world > 1:
         img, lab = img[rank:rank + 1], lab[rank:rank + 1]
-    tr = DataParallelTrainer(engine=OracleEngine(lr=0.05), base_lr=0.05, max_iterations=10, group=group, buckets=3)
+    tr = DataParallelTrainer(engine=OracleEngine(lr=0.05), base_lr=0.05, max_iterations=10, group=group, buckets=3,
+                             allreduce_dtype=wire_dtype)
     hist = []
     for _ in range(2):
         hist.append(tr.train_step(img, lab).clone())
@@ -130,3 +131,30 @@ def test_two_ranks_equal_global_batch():
     assert np.allclose(single["w"], multi["w"], rtol=1e-4, atol=2e-6)
     assert abs(single["lr"] - 0.05 * (1 - 1 / 10) ** 0.9) < 1e-12 and single["lr"] == multi["lr"]
     assert single["stats"][1, 0] != single["stats"][0, 0]            # the step really changed the loss
+
+
+def test_two_ranks_bf16_gradient_wire():
+    """allreduce_dtype=bfloat16 (BASELINE configs[2]: bf16 gradients on the wire): same protocol, gradients rounded to
+    8 mantissa bits before the sum; the weights after 2 steps stay within that rounding of the fp32-wire run."""
+    ctx = mp.get_context("spawn")
+    q1, q2 = ctx.Queue(), ctx.Queue()
+    _run(0, 1, 0, q1)
+    single = q1.get(timeout=60)
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, 2, port, q2, torch.bfloat16), daemon=True) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        multi = q2.get(timeout=240)
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert np.allclose(single["stats"][0], multi["stats"][0], rtol=2e-5, atol=1e-6)      # first loss: no gradient used yet
+    dw = np.abs(single["w"] - multi["w"]).max()
+    step = np.abs(single["w"]).max() * 0 + 0.05                                            # lr: one step moves a weight by <= lr * |g|
+    assert 0 < dw < 2 ** -7 * step * 40, dw                                               # bf16 rounding of the update, not garbage
+    assert np.allclose(single["stats"][1], multi["stats"][1], rtol=5e-3)
+
