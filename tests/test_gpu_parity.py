@@ -583,6 +583,31 @@ def test_trainer_synapse_on_synthetic_dataset(N, tmp_path):
     assert not msg.missing_keys and not msg.unexpected_keys
 
 
+@pytest.mark.parametrize("ncls,B", [(4, 1), (3, 3)])
+def test_model_other_class_counts_and_batches_vs_oracle(N, ops, ncls, B):
+    """KiTS / LiTS class counts of the reference's dataset table (train.py:88-103: 4 and 3 classes) and odd batch sizes:
+    logits, loss and every parameter gradient of one training step vs the CPU oracle (short depth to keep the oracle fast)."""
+    cfg = dict(O.TINY_224, depth=(1, 1, 2, 1), num_classes=ncls)
+    net = N.CSWinTransformer(img_size=224, num_classes=ncls, embed_dim=64, depth=[1, 1, 2, 1], split_size=[1, 2, 7, 7],
+                             num_heads=[2, 4, 8, 16], qkv_bias=True).to(DEV)
+    fill_state_dict(net).train()
+    img = det_normal(f"modelc{ncls}.x", (B, 3, 224, 224))
+    lab = det_labels(f"modelc{ncls}.lab", (B, 224, 224), ncls)
+    logits = net(T(img))
+    loss, _ = ops.ce_dice_loss(logits, T(lab))
+    loss.backward()
+    P = O.golden_params(cfg)
+    ref_logits = O.cswin_forward(P, torch.from_numpy(img), cfg)
+    ref_loss, _, _ = O.ce_dice_loss(ref_logits, torch.from_numpy(lab), ncls)
+    ref_loss.backward()
+    rel_err(logits, ref_logits, f"modelc{ncls}.logits")
+    assert abs(float(loss) - float(ref_loss)) < 1e-3 * abs(float(ref_loss))
+    params = dict(net.named_parameters())
+    assert set(params) == set(P)
+    for n in params:
+        rel_err(params[n].grad, P[n].grad, f"modelc{ncls}.grad." + n)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # bf16-operand matmul mode (BASELINE configs[2..4] name bf16).  Same fp32 oracle, looser STATED bound: operands are rounded
 # to 8 mantissa bits (relative 2^-9 each), products accumulate in fp32; observed max|diff|/rms is ~5e-3 per GEMM.
