@@ -9,6 +9,8 @@ One "step" = forward -> 0.4*CE + 0.6*Dice -> backward (-> RCCL all-reduce) -> SG
 Rank 0 prints ONE JSON line.  At N=1 it also carries
   * "roofline": the stripe-attention kernels (the kernels north_star names), timed live with HIP events on the launch
     stream, algorithmic FLOPs from SURVEY.md 8(d): 4*L*N*C per block per image forward, x2 more for backward;
+  * "roofline_dominant_by_time": the same measurement for the GEMM family (every Linear of the 26 blocks, fwd + dgrad +
+    wgrad), which is ~73 % of the step;
   * "cpu_baseline": the CPU oracle's identical training step timed on this host's cores (kind "port").
 """
 import argparse
@@ -107,13 +109,46 @@ def attention_roofline(batch, cfg, img_size=224):
     if batch == 24 and img_size == 224 and os.path.exists(pmc):
         per = json.load(open(pmc))["per_launch"]
         traffic = int(sum(2 * depth[si] * (per[f"stage{si + 1}"]["fwd_bytes"] + per[f"stage{si + 1}"]["bwd_bytes"]) for si in range(4)))
-    return {"kernel": "attn_fwd_kernel + attn_bwd_kernel (+ lepe_grad_reduce), all 26 blocks of one step", "bound": "mfma",
+    return {"kernel": "attn_fwd_kernel + attn_bwd_kernel / attn_bwd2_kernel (+ their slab reduction launch), all 26 blocks of one step", "bound": "mfma",
             "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic,
             "traffic_note": "bytes per step (52 launches); algorithmic bytes per step = %d" % int(tot_bytes),
             "algorithmic_gflop_per_step": round(tot_flops / 1e9, 2), "time_per_step_ms": round(tot_time * 1e3, 3),
             "hbm_frac_algorithmic": round(tot_bytes / tot_time / 1e9 / PEAK_HBM_GBPS, 4), "per_stage": rows}
 
+
+
+def gemm_family_roofline(batch, cfg, img_size=224):
+    """The kernel family that dominates the step by time (~73 %): every Linear of the 26 CSWinBlocks, forward / data-gradient /
+    weight-gradient, timed like the attention kernels (hipGraph replay between HIP events) through the C ABI and weighted by
+    how often each shape runs in a step.  Algorithmic FLOPs = 2*M*N*K per GEMM."""
+    from cswin_unet_amd._lib import call, lib, ptr, stream
+    E, depth = cfg.EMBED_DIM, cfg.DEPTH
+    reso0 = img_size // 4
+    g = torch.Generator(device="cpu").manual_seed(11)
+    tot_t, tot_f = 0.0, 0.0
+    for si in range(4):
+        C, L = E << si, (reso0 >> si) ** 2
+        M = batch * L
+        for N, K in ((3 * C, C), (C, C), (4 * C, C), (C, 4 * C)):
+            x, w, b = (torch.randn(*sh, generator=g).to("cuda") for sh in ((M, K), (N, K), (N,)))
+            dy = torch.randn(M, N, generator=g).to("cuda")
+            y, dx, dw, db = (torch.empty(*sh, device="cuda") for sh in ((M, N), (M, K), (N, K), (N,)))
+            nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
+            ws = torch.empty(nbytes // 4 + 4, device="cuda")
+            t = _graph_time(lambda: call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, stream()))
+            t += _graph_time(lambda: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, stream()))
+            t += _graph_time(lambda: call("cswin_linear_bwd_weight", ptr(dy), ptr(x), None, 0, None, 1, ptr(dw), ptr(db), ptr(ws), nbytes,
+                                          M, N, K, None, stream()))
+            tot_t += 2 * depth[si] * t
+            tot_f += 2 * depth[si] * 3 * 2.0 * M * N * K
+    achieved = tot_f / tot_t / 1e12
+    return {"kernel": "gemm_kernel (Linear fwd + dgrad + wgrad incl. slab reduction, 16 shapes weighted by use: 312 launches of a step)",
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
+            "algorithmic_gflop_per_step": round(tot_f / 1e9, 1), "time_per_step_ms": round(tot_t * 1e3, 3),
+            "sustained_mfma_tflops_measured": 141.0,
+            "note": "peak is the 2.4 GHz data-sheet figure; tools/micro/mfma_peak.hip (MFMAs only, no memory) sustains 137-146 TFLOP/s on this chip"}
 
 def cpu_baseline(batch, steps=2):
     """The CPU oracle's training step (same model, loss, optimiser, synthetic batch) on the host cores."""
@@ -222,6 +257,9 @@ def main():
         if world == 1 and not args.skip_roofline:
             log("[bench] attention roofline sub-benchmark ...")
             out["roofline"] = attention_roofline(args.batch, config.MODEL.CSWIN, config.DATA.IMG_SIZE)
+            if args.matmul == "fp32":
+                log("[bench] GEMM family roofline sub-benchmark ...")
+                out["roofline_dominant_by_time"] = gemm_family_roofline(args.batch, config.MODEL.CSWIN, config.DATA.IMG_SIZE)
         if world == 1 and not args.skip_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
         print(json.dumps(out), flush=True)
