@@ -184,15 +184,18 @@ class HipEngine:
         self._img, self._lab = img.clone(), lab.clone()
         self.opt.zero_grad()
         graphs = [torch.cuda.CUDAGraph()]
-        with torch.cuda.graph(graphs[0]):
+        # thread_local: RCCL's watchdog thread polls events of earlier collectives while we capture; its calls must not
+        # invalidate the capture (the default "global" mode polices every thread of the process)
+        mode = dict(capture_error_mode="thread_local")
+        with torch.cuda.graph(graphs[0], **mode):
             logits = self._forward_sums(self._img, self._lab)
         graphs.append(torch.cuda.CUDAGraph())
-        with torch.cuda.graph(graphs[1], pool=graphs[0].pool()):
+        with torch.cuda.graph(graphs[1], pool=graphs[0].pool(), **mode):
             boundary = self._backward_decoder(logits, self._lab, dice_grad_scale)
         if boundary is not None:
             for phase in self._encoder_phases(boundary):
                 graphs.append(torch.cuda.CUDAGraph())
-                with torch.cuda.graph(graphs[-1], pool=graphs[0].pool()):
+                with torch.cuda.graph(graphs[-1], pool=graphs[0].pool(), **mode):
                     phase()
         self._graphs = graphs
 
