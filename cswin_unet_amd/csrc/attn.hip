@@ -96,6 +96,8 @@ __device__ __forceinline__ void store_lepe_partial(const AttnParams& p, const At
         if (p.stamps && threadIdx.x == 0) p.stamps[(long)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); \
     } while (0)
 
+__host__ __device__ __forceinline__ int w_N_rows(const AttnParams& p) { return (p.br[0].H_sp * p.br[0].W_sp + 3) / 4 * 4; }
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -314,15 +316,16 @@ __device__ __forceinline__ float row16_sum(float v) {
 template <int NT>
 __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
     constexpr int NP = 16 * NT;
-    constexpr int LDS_S = NP + 4;                 // dS row stride
     constexpr int NTHREADS = 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qs = smem;                    // [NP][LDT]   (aliased by the LePE-gradient scratch at the end)
     float* Ks = Qs + NP * LDT;
     float* Vs = Ks + NP * LDT;
     float* Ds = Vs + NP * LDT;           // dO
+    const int LDS_S = p.ds_stride;       // dS row stride: >= N, = 4 (mod 8); N = 56 -> 60 lets three workgroups share a CU
     float* dSs = Ds + NP * LDT;          // [NP q][LDS_S]
-    float* lse_s = dSs + NP * LDS_S;     // [NP]
+    const int NR = (w_N_rows(p));         // dS rows kept: the real queries, rounded up to 4
+    float* lse_s = dSs + NR * LDS_S;     // [NP]
     float* del_s = lse_s + NP;           // [NP]
     float* Wl = del_s + NP;              // [9][32]
 
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
             dVt[1] = mfma4(dop[16], P[qt][r], dVt[1]);
             dKt[0] = mfma4(qp[0], ds[r], dKt[0]);
             dKt[1] = mfma4(qp[16], ds[r], dKt[1]);
-            dSs[qrow * LDS_S + 16 * kw + li] = ds[r];
+            if (16 * kw + li < LDS_S && qrow < NR) dSs[qrow * LDS_S + 16 * kw + li] = ds[r];   // beyond the stride = next row
         }
     }
     // lane holds dV^T / dK^T [d = 16 df + 4 kq + e][key = tk]: add LePE^T(dO) to dV and store
@@ -455,7 +458,9 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
         f32x4 dQt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
-            const f32x4 ds = *reinterpret_cast<const f32x4*>(&dSs[(16 * qt + li) * LDS_S + 16 * kt + 4 * kq]);
+            // columns beyond the stride read the head of the next row (finite) against K rows that are zero
+            // (rows >= NR are padded queries: any finite row will do, their dQ columns are never stored)
+            const f32x4 ds = *reinterpret_cast<const f32x4*>(&dSs[min(16 * qt + li, NR - 1) * LDS_S + 16 * kt + 4 * kq]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float* kp = &Ks[(16 * kt + 4 * kq + r) * LDT + li];
@@ -1180,28 +1185,23 @@ int launch_fwd(const AttnParams& p, int nwg, hipStream_t st) {
     return CSWIN_OK;
 }
 
-template <int NT>
-size_t bwd_lds_bytes() {
-    return (size_t)(4 * 16 * NT * LDT + 16 * NT * (16 * NT + 4) + 2 * 16 * NT + 9 * HD) * sizeof(float);
-}
-
-template <int NT>
-int launch_bwd(const AttnParams& p, int nwg, hipStream_t st) {
-    const size_t lds = bwd_lds_bytes<NT>();
-    static bool reserved = false;
-    if (lds > 64 * 1024 && !reserved) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { cswin_set_error("attn_bwd: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return CSWIN_ERR_HIP; }
-        reserved = true;
-    }
-    hipLaunchKernelGGL((attn_bwd_kernel<NT>), dim3(nwg), dim3(64 * NT), lds, st, p);
-    return CSWIN_OK;
-}
-
 inline int ds_stride_for(int N) {            // smallest stride >= N with stride = 4 (mod 8): 16-B aligned rows, and the four
     int s = (N + 3) / 4 * 4;                 // row groups of a dS column write land in distinct banks
     while (s % 8 != 4) s += 4;
     return s;
+}
+
+template <int NT>
+int launch_bwd(const AttnParams& p, int nwg, hipStream_t st) {
+    const size_t lds = (size_t)(4 * 16 * NT * LDT + w_N_rows(p) * p.ds_stride + 2 * 16 * NT + 9 * HD) * sizeof(float);
+    static size_t reserved = 0;
+    if (lds > 64 * 1024 && lds > reserved) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { cswin_set_error("attn_bwd: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return CSWIN_ERR_HIP; }
+        reserved = lds;
+    }
+    hipLaunchKernelGGL((attn_bwd_kernel<NT>), dim3(nwg), dim3(64 * NT), lds, st, p);
+    return CSWIN_OK;
 }
 
 template <int NT>

@@ -26,7 +26,9 @@ h = lib(); h.cswin_debug_set_attn_stamps.argtypes = [ctypes.c_void_p]
 h.cswin_debug_set_attn_stamps(ctypes.c_void_p(st.data_ptr())); bwd(); torch.cuda.synchronize(); h.cswin_debug_set_attn_stamps(None)
 s = st.cpu().numpy(); s = s[s[:, 0] != 0]
 print(f"stage {si+1}: {len(s)} workgroups")
-names = ["P0 load -> LDS", "P1 delta + LePE wgrad", "P2 fused loop + dK/dV", "barrier + K image", "P3 dQ", "-"]
+names = (["P0 load -> LDS", "P1 delta + LePE wgrad", "P2 fused loop + dK/dV", "barrier + K image", "P3 dQ", "slab reduce + store"]
+         if os.environ.get("CSWIN_ATTN_BWD_KERNEL", "2" if si == 2 else "1") == "2" else
+         ["load -> LDS", "loop1 (S, dP, delta)", "loop2 (dV, dK, dS)", "barrier + dQ", "LePE wgrad", "slab reduce + store"])
 for k, nm in enumerate(names):
     d = s[:, k + 1] - s[:, k]
     print(f"  {nm:24s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f} shader cycles (s_memtime)")
