@@ -112,14 +112,16 @@ template <bool THIN, int SIGN>
 __device__ __forceinline__ f32x4 lepe_taps4(const AttnBranch& br, const float* __restrict__ src, const float* __restrict__ Wl,
                                             int rr, int cc, int self_t, int d0, f32x4 acc) {
     if constexpr (THIN) {
+        // a 1 x W or H x 1 stripe is a line: the neighbours of token t are t - 1, t, t + 1 (rr / cc are not used)
         const bool row = br.H_sp == 1;
+        const int n = br.H_sp * br.W_sp;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int ky = row ? 1 : j, kx = row ? j : 1;
-            const int r2 = rr + SIGN * (ky - 1), c2 = cc + SIGN * (kx - 1);
-            const bool ok = (unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp;
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(&Wl[(ky * 3 + kx) * HD + d0]);
-            const f32x4 vv = *reinterpret_cast<const f32x4*>(&src[(ok ? r2 * br.W_sp + c2 : self_t) * LDT + d0]);
+            const int tap = row ? 3 + j : 3 * j + 1;
+            const int t2 = self_t + SIGN * (j - 1);
+            const bool ok = (unsigned)t2 < (unsigned)n;
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(&Wl[tap * HD + d0]);
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(&src[(ok ? t2 : self_t) * LDT + d0]);
             acc += (ok ? 1.f : 0.f) * wv * vv;
         }
     } else {
@@ -142,12 +144,12 @@ template <bool THIN>
 __device__ __forceinline__ void lepe_wgrad_taps(const AttnBranch& br, const float* __restrict__ Vs, int rr, int cc, int t, int d,
                                                 float g, float* a) {
     if constexpr (THIN) {
-        const bool row = br.H_sp == 1;
+        const int n = br.H_sp * br.W_sp;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {                           // a[j] holds tap (1, j) or (j, 1); expanded by the caller
-            const int r2 = rr + (row ? 0 : j - 1), c2 = cc + (row ? j - 1 : 0);
-            const bool ok = (unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp;
-            const float vv = Vs[(ok ? r2 * br.W_sp + c2 : t) * LDT + d];
+            const int t2 = t + j - 1;                           // the stripe is a line (rr / cc are not used)
+            const bool ok = (unsigned)t2 < (unsigned)n;
+            const float vv = Vs[(ok ? t2 : t) * LDT + d];
             a[j] += ok ? g * vv : 0.f;
         }
     } else {
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnPa
             }
         // lane now holds O^T[d = 16 df + 4 kq + e][q = li]
         if (qvalid) {
-            const int rr = tq / br.W_sp, cc = tq - rr * br.W_sp;
+            const int rr = thin ? 0 : tq / br.W_sp, cc = thin ? 0 : tq - rr * br.W_sp;      // thin stripes: unused
 #pragma unroll
             for (int df = 0; df < 2; ++df) {
                 const int d0 = 16 * df + 4 * kq;
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
     // lane holds dV^T / dK^T [d = 16 df + 4 kq + e][key = tk]: add LePE^T(dO) to dV and store
     if (kvalid) {
         const int lk = token_of(br, w, p.reso, tk);
-        const int rr = tk / br.W_sp, cc = tk - rr * br.W_sp;
+        const int rr = thin ? 0 : tk / br.W_sp, cc = thin ? 0 : tk - rr * br.W_sp;          // thin stripes: unused
 #pragma unroll
         for (int df = 0; df < 2; ++df) {
             const int d0 = 16 * df + 4 * kq;
@@ -488,9 +490,12 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
         for (int i = 0; i < 10; ++i) a[i] = 0.f;
         for (int t = 2 * wave + (lane >> 5); t < N; t += 2 * NT) {
             const float g = Ds[t * LDT + d];
-            const int rr = t / br.W_sp, cc = t - rr * br.W_sp;
-            if (thin) lepe_wgrad_taps<true>(br, Vs, rr, cc, t, d, g, a);
-            else lepe_wgrad_taps<false>(br, Vs, rr, cc, t, d, g, a);
+            if (thin) {
+                lepe_wgrad_taps<true>(br, Vs, 0, 0, t, d, g, a);
+            } else {
+                const int rr = t / br.W_sp, cc = t - rr * br.W_sp;
+                lepe_wgrad_taps<false>(br, Vs, rr, cc, t, d, g, a);
+            }
             a[9] += g;
         }
         if (thin) {                                             // a[0..2] -> taps (1, j) or (j, 1); the other six are zero
@@ -643,7 +648,7 @@ __global__ __launch_bounds__(64 * NT, (NT <= 4 ? 4 : 2)) void attn_bwd2_kernel(A
             const bool tv = t < N;
             const int tc = tv ? t : 0;
             const float g = tv ? Ds[tc * LDT + dch] : 0.f;
-            const int rr = tc / br.W_sp, cc = tc - rr * br.W_sp;
+            const int rr = thin ? 0 : tc / br.W_sp, cc = thin ? 0 : tc - rr * br.W_sp;         // thin stripes: unused
             float b[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) b[i] = 0.f;
@@ -736,7 +741,7 @@ __global__ __launch_bounds__(64 * NT, (NT <= 4 ? 4 : 2)) void attn_bwd2_kernel(A
     }
     // lane holds dV^T / dK^T [d = 16 df + 4 kq + e][key = tk]: add LePE^T(dO) to dV and store
     if (kvalid) {
-        const int rr = tk / br.W_sp, cc = tk - rr * br.W_sp;
+        const int rr = thin ? 0 : tk / br.W_sp, cc = thin ? 0 : tk - rr * br.W_sp;          // thin stripes: unused
 #pragma unroll
         for (int df = 0; df < 2; ++df) {
             const int d0 = 16 * df + 4 * kq;
