@@ -168,18 +168,24 @@ __device__ __forceinline__ void lepe_wgrad_taps(const AttnBranch& br, const floa
 // =====================================================================================
 // forward
 // =====================================================================================
-template <int NT>
-__global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnParams p) {
+// QS = 2: the query tiles of a (window, head) are split over two workgroups (each stages the whole K / V stripe): with
+// 384 units on 256 CUs half the CUs would otherwise carry two whole units and set the kernel time; 768 half-units are
+// three per CU.  The two halves are `units` apart in the grid, i.e. on the same XCD / L2 when units % 8 == 0.
+template <int NT, int QS>
+__global__ __launch_bounds__(64 * (QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8))) void attn_fwd_kernel(AttnParams p, int units) {
     constexpr int NP = 16 * NT;
-    constexpr int NW = NT < 8 ? NT : 8;
+    constexpr int NW = QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8);
+    static_assert(QS == 1 || NT <= 8, "query split only for windows of up to 128 tokens");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;                  // [NP][LDT]
     float* Vs = Ks + NP * LDT;         // [NP][LDT]
     float* Wl = Vs + NP * LDT;         // [10][32]: 9 taps + bias of this head's channels
 
-    const WgInfo w = decode_wg(p, blockIdx.x);
+    const int half = QS == 2 ? (int)blockIdx.x / units : 0;
+    const WgInfo w = decode_wg(p, QS == 2 ? (int)blockIdx.x - half * units : (int)blockIdx.x);
     const AttnBranch& br = p.br[w.bi];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qt0 = half * NW + wave;             // this wave's first (QS = 2: only) query tile
     const int li = lane & 15, kq = lane >> 4;
     const int L = p.reso * p.reso, C3 = 3 * p.C;
     const int ch0 = br.c0 + w.g * p.hd;           // first channel of this head inside C
@@ -187,13 +193,14 @@ __global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnPa
     const float* qkv_b = p.qkv + (long)w.b * L * C3;
     const bool thin = br.H_sp == 1 || br.W_sp == 1;       // wave-uniform
 
+    ATTN_STAMP(0);
     // this wave's first query tile: issue its Q loads first so their latency overlaps the K/V staging below
     f32x4 q0_pre = {0.f, 0.f, 0.f, 0.f}, q1_pre = q0_pre;
     int lq_pre = 0;
     {
-        const int tq = 16 * wave + li;
-        if (wave < NT && tq < N) lq_pre = token_of(br, w, p.reso, tq);
-        if (wave < NT && tq < N && 8 * kq < p.hd) {
+        const int tq = 16 * qt0 + li;
+        if (qt0 < NT && tq < N) lq_pre = token_of(br, w, p.reso, tq);
+        if (qt0 < NT && tq < N && 8 * kq < p.hd) {
             const float* src = qkv_b + (long)lq_pre * C3 + ch0 + 8 * kq;
             q0_pre = *reinterpret_cast<const f32x4*>(src);
             q1_pre = *reinterpret_cast<const f32x4*>(src + 4);
@@ -217,15 +224,16 @@ __global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnPa
         Wl[i] = ch >= p.hd ? 0.f : (tap < 9 ? br.lepe_w[cb * 9 + tap] : br.lepe_b[cb]);
     }
     __syncthreads();
+    ATTN_STAMP(1);
 
-    for (int qt = wave; qt < NT; qt += NW) {
+    for (int qt = qt0; qt < NT; qt += QS == 2 ? NT : NW) {
         const int tq = 16 * qt + li;
         const bool qvalid = tq < N;
         int lq = lq_pre;
         float qr[8];
         {
             f32x4 q0 = q0_pre, q1 = q1_pre;
-            if (qt != wave) {                       // only when a wave owns more than one query tile (N > 128)
+            if (qt != qt0) {                        // only when a wave owns more than one query tile (N > 128)
                 q0 = f32x4{0.f, 0.f, 0.f, 0.f};
                 q1 = q0;
                 lq = qvalid ? token_of(br, w, p.reso, tq) : 0;
@@ -275,6 +283,7 @@ __global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnPa
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
+        if (qt == qt0) ATTN_STAMP(2);
 
         // O^T[d][q] = sum_key V[key][d] * P^T[key][q]; the P accumulator tile is the B operand as it stands
         f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -287,6 +296,7 @@ __global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnPa
                 o[1] = mfma4(vp[16], s[kt][r], o[1]);
             }
         // lane now holds O^T[d = 16 df + 4 kq + e][q = li]
+        if (qt == qt0) ATTN_STAMP(3);
         if (qvalid) {
             const int rr = thin ? 0 : tq / br.W_sp, cc = thin ? 0 : tq - rr * br.W_sp;      // thin stripes: unused
 #pragma unroll
@@ -300,6 +310,7 @@ __global__ __launch_bounds__(64 * (NT < 8 ? NT : 8)) void attn_fwd_kernel(AttnPa
             if (kq == 0) p.lse[((long)w.b * p.heads_total + br.head0 + w.g) * L + lq] = mx + __logf(sum);
         }
     }
+    ATTN_STAMP(4);
 }
 
 // =====================================================================================
@@ -1182,11 +1193,20 @@ int launch_fwd(const AttnParams& p, int nwg, hipStream_t st) {
     const size_t lds = (size_t)(2 * 16 * NT * LDT + 10 * HD) * sizeof(float);
     static bool reserved = false;       // one-time, idempotent: not a stream operation, keep it out of graph captures
     if (lds > 64 * 1024 && !reserved) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { cswin_set_error("attn_fwd: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return CSWIN_ERR_HIP; }
         reserved = true;
     }
-    hipLaunchKernelGGL((attn_fwd_kernel<NT>), dim3(nwg), dim3(64 * NW), lds, st, p);
+    if constexpr (NT <= 8) {
+        // few units relative to the 256 CUs: split the query tiles over two workgroups per unit (see the kernel)
+        static const char* force = getenv("CSWIN_ATTN_FWD_QSPLIT");                      // tuning aid: "1" or "2"
+        const bool split = force ? force[0] == '2' : (nwg < 1024 && nwg % 256 != 0 && NT >= 6);   // measured: pays at N = 98, not at N = 49
+        if (split) {
+            hipLaunchKernelGGL((attn_fwd_kernel<NT, 2>), dim3(2 * nwg), dim3(64 * ((NT + 1) / 2)), lds, st, p, nwg);
+            return CSWIN_OK;
+        }
+    }
+    hipLaunchKernelGGL((attn_fwd_kernel<NT, 1>), dim3(nwg), dim3(64 * NW), lds, st, p, nwg);
     return CSWIN_OK;
 }
 
@@ -1243,6 +1263,7 @@ int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* co
     CSWIN_REQUIRE(qkv && y && lse && lepe_w && lepe_b, CSWIN_ERR_SHAPE, "attn_fwd: null pointer");
     for (int i = 0; i < nbranch; ++i) { p.br[i].lepe_w = lepe_w[i]; p.br[i].lepe_b = lepe_b[i]; }
     p.qkv = qkv; p.y = y; p.lse = lse;
+    p.stamps = g_attn_stamps;
     hipStream_t st = (hipStream_t)stream;
     switch (nt) {
         case 1: case 2: case 3: case 4: rc = launch_fwd<4>(p, nwg, st); break;

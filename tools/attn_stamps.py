@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""In-kernel timeline of attn_bwd: attn_stamps.py stage(1..4) [batch]"""
+"""In-kernel timeline of the attention kernels: attn_stamps.py stage(1..4) [batch] [fwd]"""
 import os, sys, ctypes
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cswin_unet_amd._lib import call, lib, ptr, stream
-si = int(sys.argv[1]) - 1; batch = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+si = int(sys.argv[1]) - 1; batch = int(sys.argv[2]) if len(sys.argv) > 2 else 24; FWD = len(sys.argv) > 3 and sys.argv[3] == "fwd"
 E, heads, split = 64, [2, 4, 8, 16], [1, 2, 7, 7]
 C, reso = E << si, 56 >> si; L = reso * reso
 single = si == 3
@@ -23,14 +23,17 @@ for _ in range(3): bwd()
 torch.cuda.synchronize()
 st = torch.zeros(1 << 16, 8, dtype=torch.int64, device=dev)
 h = lib(); h.cswin_debug_set_attn_stamps.argtypes = [ctypes.c_void_p]
-h.cswin_debug_set_attn_stamps(ctypes.c_void_p(st.data_ptr())); bwd(); torch.cuda.synchronize(); h.cswin_debug_set_attn_stamps(None)
+def fwd(): call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(lse), batch, reso, C, nb, ha, ia, split[si], 0.0, stream())
+h.cswin_debug_set_attn_stamps(ctypes.c_void_p(st.data_ptr())); (fwd if FWD else bwd)(); torch.cuda.synchronize(); h.cswin_debug_set_attn_stamps(None)
 s = st.cpu().numpy(); s = s[s[:, 0] != 0]
 print(f"stage {si+1}: {len(s)} workgroups")
 names = (["P0 load -> LDS", "P1 delta + LePE wgrad", "P2 fused loop + dK/dV", "barrier + K image", "P3 dQ", "slab reduce + store"]
          if os.environ.get("CSWIN_ATTN_BWD_KERNEL", "2" if si == 2 else "1") == "2" else
          ["load -> LDS", "loop1 (S, dP, delta)", "loop2 (dV, dK, dS)", "barrier + dQ", "LePE wgrad", "slab reduce + store"])
+if FWD: names = ["K/V -> LDS", "S + softmax (tile 0)", "PV (tile 0)", "LePE + store (+ more tiles)"]
 for k, nm in enumerate(names):
     d = s[:, k + 1] - s[:, k]
     print(f"  {nm:24s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f} shader cycles (s_memtime)")
-d = s[:, 6] - s[:, 0]; print(f"  {'total':24s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f}")
-d = s[:, 6].max() - s[:, 0].min(); print(f"  kernel span {d} cycles")
+E = 4 if FWD else 6
+d = s[:, E] - s[:, 0]; print(f"  {'total':24s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f}")
+d = s[:, E].max() - s[:, 0].min(); print(f"  kernel span {d} cycles")
