@@ -10,6 +10,7 @@
 // Everything is on the (B, L, C) token layout.  HBM-bound: one pass over e and z (z neighbours
 // come from L1/L2), one coalesced write of out.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -157,6 +158,127 @@ __global__ __launch_bounds__(256) void carafe_bwd_z_kernel(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused backward for the model's last stage (CARAFE4 + fused head: S = 4, Cz = 16; 224 x 224 logits at B = 24 are 77 MB of
+// dout).  The three generic kernels below read dout three times (de, dz, dbias) and gather it with 4-B / 16-B pieces; here
+// one workgroup owns an 8 x 8 tile of low-resolution pixels and reads the 16 x 16 block D[p] = dout[4h..4h+3][4w..4w+3][0..15]
+// of every pixel of the tile + a one-pixel halo exactly once per use, as 256-B row segments, and the per-pixel
+// contractions run on the matrix pipes (v_mfma_f32_16x16x4_f32, exact fp32):
+//   G[p]   (9 x 16) = Wt[p] (9 taps x 16 sub-pixels) . D[p] (16 sub-pixels x 16 channels)     -> LDS, tile + halo
+//   dWt[p] (9 x 16) = Znbr[p] (9 taps x 16 channels) . D[p]^T                                   -> softmax backward -> de
+//   dz[n][c] = sum_k G[n - off_k][k][c]   (9 LDS reads per output),   dbias[c] = sum_{p, s} D[p][s][c]
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int C4_T = 8;                       // tile edge (low-resolution pixels)
+constexpr int C4_HALO = C4_T + 2;
+constexpr int C4_NP = C4_HALO * C4_HALO;      // 100 pixels whose G is needed
+
+__device__ __forceinline__ f32x4 carafe_mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+__global__ __launch_bounds__(256) void carafe4_bwd_fused_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+                                                                 const float* __restrict__ wt_save, float* __restrict__ de,
+                                                                 float* __restrict__ dz, float* __restrict__ dbias_part,
+                                                                 int B, int H, int W, int tiles_x, int tiles_y) {
+    constexpr int S = 4, S2 = 16, Cz = 16;
+    __shared__ __attribute__((aligned(16))) float Gs[C4_NP * 9 * Cz];      // [pixel][tap][channel]   57.6 KB
+    __shared__ __attribute__((aligned(16))) float zt[C4_NP * Cz];          // z of the tile + halo       6.4 KB
+    __shared__ float bred[4][Cz];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int h0 = ty * C4_T - 1, w0 = tx * C4_T - 1;           // top-left of the halo region
+
+    for (int i = tid; i < C4_NP * (Cz / 4); i += 256) {
+        const int pl = i >> 2, c4 = i & 3;
+        const int h = h0 + pl / C4_HALO, w = w0 + pl % C4_HALO;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W)
+            v = *reinterpret_cast<const f32x4*>(z + (((long)b * H + h) * W + w) * Cz + 4 * c4);
+        *reinterpret_cast<f32x4*>(&zt[pl * Cz + 4 * c4]) = v;
+    }
+    __syncthreads();
+
+    float bsum = 0.f;                                            // dbias partial: lane (li = channel), its kq's share
+    for (int pl = wave; pl < C4_NP; pl += 4) {
+        const int ph = pl / C4_HALO, pw = pl - ph * C4_HALO;
+        const int h = h0 + ph, w = w0 + pw;
+        const bool inside = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;        // wave-uniform
+        float* Gp = &Gs[pl * 9 * Cz];
+        if (!inside) {
+            for (int i = lane; i < 9 * Cz; i += 64) Gp[i] = 0.f;
+            continue;
+        }
+        const long pix = ((long)b * H + h) * W + w;
+        const float* wp = wt_save + pix * (9 * S2);
+        const float* drow = dout + (((long)b * H * S + h * S) * (W * S) + w * S) * Cz;       // hi-res pixel (4h, 4w)
+        const long hstride = (long)W * S * Cz;                                               // one hi-res row down
+        // ---- G = Wt . D : A lane (tap li, sub-pixel 4j + kq), B lane (channel li, sub-pixel 4j + kq = row j, column kq) ----
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        float dsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = li < 9 ? wp[li * S2 + 4 * j + kq] : 0.f;
+            const float d = drow[j * hstride + kq * Cz + li];    // 4 sub-pixels x 16 channels = 256 contiguous bytes
+            g = carafe_mfma4(a, d, g);
+            dsum += d;
+        }
+        // C layout: lane holds G[tap = 4 kq + r][channel = li]
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * kq + r < 9) Gp[(4 * kq + r) * Cz + li] = g[r];
+        const bool interior = ph >= 1 && ph <= C4_T && pw >= 1 && pw <= C4_T;                 // wave-uniform
+        if (!interior) continue;
+        bsum += dsum;
+        // ---- dWt = Znbr . D^T : A lane (tap li, channels 4 kq + j), B lane (sub-pixel li, channels 4 kq + j) ----
+        f32x4 za = {0.f, 0.f, 0.f, 0.f};
+        if (li < 9) {
+            const int nh = ph + li / 3 - 1, nw = pw + li % 3 - 1;                           // neighbour inside the halo region
+            za = *reinterpret_cast<const f32x4*>(&zt[(nh * C4_HALO + nw) * Cz + 4 * kq]);    // zeros outside the image
+        }
+        const f32x4 db = *reinterpret_cast<const f32x4*>(drow + (li >> 2) * hstride + (li & 3) * Cz + 4 * kq);
+        f32x4 dw = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dw = carafe_mfma4(za[j], db[j], dw);
+        // lane holds dWt[tap = 4 kq + r][sub-pixel = li]; softmax backward over the 9 taps of this sub-pixel
+        float wv[4], dot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            wv[r] = 4 * kq + r < 9 ? wp[(4 * kq + r) * S2 + li] : 0.f;
+            dot += wv[r] * dw[r];
+        }
+        dot += __shfl_xor(dot, 16, 64);
+        dot += __shfl_xor(dot, 32, 64);
+        float* dep = de + pix * (9 * S2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * kq + r < 9) dep[(4 * kq + r) * S2 + li] = wv[r] * (dw[r] - dot);
+    }
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (lane < Cz) bred[wave][lane] = bsum;
+    __syncthreads();
+    if (tid < Cz && dbias_part) dbias_part[(long)blockIdx.x * Cz + tid] = bred[0][tid] + bred[1][tid] + bred[2][tid] + bred[3][tid];
+
+    // ---- dz of the 64 interior pixels: 4 lanes x 16 B per pixel ----
+    {
+        const int n = tid >> 2, c4 = tid & 3;
+        const int ph = 1 + n / C4_T, pw = 1 + n % C4_T;
+        const int h = h0 + ph, w = w0 + pw;
+        if (h < H && w < W) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                // source pixel whose k-th neighbour is (h, w): (h - (k/3 - 1), w - (k%3 - 1)); outside the image its G is 0
+                const int sh = ph - (k / 3 - 1), sw = pw - (k % 3 - 1);
+                acc += *reinterpret_cast<const f32x4*>(&Gs[((sh * C4_HALO + sw) * 9 + k) * Cz + 4 * c4]);
+            }
+            *reinterpret_cast<f32x4*>(dz + (((long)b * H + h) * W + w) * Cz + 4 * c4) = acc;
+        }
+    }
+}
+
 // column sums of a (rows, C) matrix: partial[blk][C] then a second pass
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
                                                               long rows, int C) {
@@ -214,8 +336,12 @@ int cswin_carafe_fwd(const float* e, const float* z, const float* bias, float* o
     return CSWIN_OK;
 }
 
+static bool carafe4_fused_ok(int H, int W, int Cz, int S) { return S == 4 && Cz == 16 && H % C4_T == 0 && W % C4_T == 0; }
+
 size_t cswin_carafe_bwd_workspace(int B, int H, int W, int Cz, int S) {
-    return (size_t)colsum_blocks((long)B * H * W * S * S, Cz) * Cz * sizeof(float);
+    size_t generic = (size_t)colsum_blocks((long)B * H * W * S * S, Cz) * Cz * sizeof(float);
+    size_t fused = carafe4_fused_ok(H, W, Cz, S) ? (size_t)B * (H / C4_T) * (W / C4_T) * Cz * sizeof(float) : 0;
+    return generic > fused ? generic : fused;
 }
 
 // dout (B, (S*H)*(S*W), Cz) -> de (B, H*W, 9*S*S), dz (B, H*W, Cz), dbias (Cz) (may be NULL)
@@ -227,6 +353,18 @@ int cswin_carafe_bwd(const float* dout, const float* z, const float* wt_save, fl
     const int groups = 256 / carafe_lpr(Cz);
     hipStream_t st = (hipStream_t)stream;
     const long items = (long)B * H * W * S * S, pixels = (long)B * H * W;
+    static const bool no_fused = getenv("CSWIN_CARAFE_GENERIC") != nullptr;                  // tuning aid
+    if (carafe4_fused_ok(H, W, Cz, S) && !no_fused) {
+        const int tx = W / C4_T, ty = H / C4_T, nblk = B * tx * ty;
+        hipLaunchKernelGGL(carafe4_bwd_fused_kernel, dim3(nblk), dim3(256), 0, st, dout, z, wt_save, de, dz,
+                           dbias ? (float*)workspace : nullptr, B, H, W, tx, ty);
+        CSWIN_LAUNCH_CHECK();
+        if (dbias) {
+            launch_rows_sum((const float*)workspace, dbias, nullptr, 0, Cz, nblk, Cz, st);
+            CSWIN_LAUNCH_CHECK();
+        }
+        return CSWIN_OK;
+    }
     if (S == 2) {
         hipLaunchKernelGGL(carafe_bwd_e_kernel<2>, dim3(grid_for(items, groups)), dim3(256), 0, st, dout, z, wt_save, de, B, H, W, Cz);
         hipLaunchKernelGGL(carafe_bwd_z_kernel<2>, dim3(grid_for(pixels, groups)), dim3(256), 0, st, dout, wt_save, dz, B, H, W, Cz);
