@@ -174,14 +174,16 @@ constexpr int C4_NP = C4_HALO * C4_HALO;      // 100 pixels whose G is needed
 
 __device__ __forceinline__ f32x4 carafe_mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-__global__ __launch_bounds__(256) void carafe4_bwd_fused_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+constexpr int C4_WAVES = 8;                   // waves per workgroup (two workgroups of 64 KB LDS share a CU)
+
+__global__ __launch_bounds__(64 * C4_WAVES) void carafe4_bwd_fused_kernel(const float* __restrict__ dout, const float* __restrict__ z,
                                                                  const float* __restrict__ wt_save, float* __restrict__ de,
                                                                  float* __restrict__ dz, float* __restrict__ dbias_part,
                                                                  int B, int H, int W, int tiles_x, int tiles_y) {
     constexpr int S = 4, S2 = 16, Cz = 16;
     __shared__ __attribute__((aligned(16))) float Gs[C4_NP * 9 * Cz];      // [pixel][tap][channel]   57.6 KB
     __shared__ __attribute__((aligned(16))) float zt[C4_NP * Cz];          // z of the tile + halo       6.4 KB
-    __shared__ float bred[4][Cz];
+    __shared__ float bred[C4_WAVES][Cz];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     int t = blockIdx.x;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void carafe4_bwd_fused_kernel(const float* __r
     const int b = t / tiles_y;
     const int h0 = ty * C4_T - 1, w0 = tx * C4_T - 1;           // top-left of the halo region
 
-    for (int i = tid; i < C4_NP * (Cz / 4); i += 256) {
+    for (int i = tid; i < C4_NP * (Cz / 4); i += 64 * C4_WAVES) {
         const int pl = i >> 2, c4 = i & 3;
         const int h = h0 + pl / C4_HALO, w = w0 + pl % C4_HALO;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -201,68 +203,96 @@ __global__ __launch_bounds__(256) void carafe4_bwd_fused_kernel(const float* __r
     __syncthreads();
 
     float bsum = 0.f;                                            // dbias partial: lane (li = channel), its kq's share
-    for (int pl = wave; pl < C4_NP; pl += 4) {
-        const int ph = pl / C4_HALO, pw = pl - ph * C4_HALO;
-        const int h = h0 + ph, w = w0 + pw;
-        const bool inside = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;        // wave-uniform
-        float* Gp = &Gs[pl * 9 * Cz];
-        if (!inside) {
-            for (int i = lane; i < 9 * Cz; i += 64) Gp[i] = 0.f;
-            continue;
+    // Each wave walks its pixels four at a time: all global loads of the four (reassembly weights as A operand, the D block
+    // in both operand layouts, the weights again in the accumulator layout) are issued before any of them is consumed, so
+    // a wave has ~1 KB x 4 in flight instead of one dependent load chain per pixel.
+    constexpr int PB = 4;
+    for (int pl0 = wave * PB; pl0 < C4_NP; pl0 += C4_WAVES * PB) {
+        bool inside[PB], interior[PB];
+        long pix[PB];
+        float av[PB][4], dv[PB][4], wv[PB][4];
+        f32x4 db[PB];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int pl = pl0 + u;
+            const int ph = pl / C4_HALO, pw = pl - ph * C4_HALO;
+            const int h = h0 + ph, w = w0 + pw;
+            inside[u] = pl < C4_NP && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;        // wave-uniform
+            interior[u] = inside[u] && ph >= 1 && ph <= C4_T && pw >= 1 && pw <= C4_T;
+            pix[u] = ((long)b * H + h) * W + w;
+            db[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) av[u][j] = dv[u][j] = wv[u][j] = 0.f;
+            if (!inside[u]) continue;
+            const float* wp = wt_save + pix[u] * (9 * S2);
+            const float* drow = dout + (((long)b * H * S + h * S) * (W * S) + w * S) * Cz;   // hi-res pixel (4h, 4w)
+            const long hstride = (long)W * S * Cz;                                           // one hi-res row down
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (li < 9) av[u][j] = wp[li * S2 + 4 * j + kq];                              // A: tap li, sub-pixel 4j + kq
+                dv[u][j] = drow[j * hstride + kq * Cz + li];      // B: channel li, sub-pixel (row j, column kq): 256-B segments
+            }
+            if (interior[u]) {
+                db[u] = *reinterpret_cast<const f32x4*>(drow + (li >> 2) * hstride + (li & 3) * Cz + 4 * kq);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * kq + r < 9) wv[u][r] = wp[(4 * kq + r) * S2 + li];
+            }
         }
-        const long pix = ((long)b * H + h) * W + w;
-        const float* wp = wt_save + pix * (9 * S2);
-        const float* drow = dout + (((long)b * H * S + h * S) * (W * S) + w * S) * Cz;       // hi-res pixel (4h, 4w)
-        const long hstride = (long)W * S * Cz;                                               // one hi-res row down
-        // ---- G = Wt . D : A lane (tap li, sub-pixel 4j + kq), B lane (channel li, sub-pixel 4j + kq = row j, column kq) ----
-        f32x4 g = {0.f, 0.f, 0.f, 0.f};
-        float dsum = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float a = li < 9 ? wp[li * S2 + 4 * j + kq] : 0.f;
-            const float d = drow[j * hstride + kq * Cz + li];    // 4 sub-pixels x 16 channels = 256 contiguous bytes
-            g = carafe_mfma4(a, d, g);
-            dsum += d;
+        for (int u = 0; u < PB; ++u) {
+            const int pl = pl0 + u;
+            if (pl >= C4_NP) continue;
+            float* Gp = &Gs[pl * 9 * Cz];
+            if (!inside[u]) {
+                for (int i = lane; i < 9 * Cz; i += 64) Gp[i] = 0.f;
+                continue;
+            }
+            // ---- G = Wt . D ----
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g = carafe_mfma4(av[u][j], dv[u][j], g);
+            // C layout: lane holds G[tap = 4 kq + r][channel = li]
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * kq + r < 9) Gp[(4 * kq + r) * Cz + li] = g[r];
+            if (!interior[u]) continue;
+            bsum += dv[u][0] + dv[u][1] + dv[u][2] + dv[u][3];
+            // ---- dWt = Znbr . D^T : A lane (tap li, channels 4 kq + j), B lane (sub-pixel li, channels 4 kq + j) ----
+            const int ph = pl / C4_HALO, pw = pl - ph * C4_HALO;
+            f32x4 za = {0.f, 0.f, 0.f, 0.f};
+            if (li < 9) {
+                const int nh = ph + li / 3 - 1, nw = pw + li % 3 - 1;                       // neighbour inside the halo region
+                za = *reinterpret_cast<const f32x4*>(&zt[(nh * C4_HALO + nw) * Cz + 4 * kq]);   // zeros outside the image
+            }
+            f32x4 dw = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dw = carafe_mfma4(za[j], db[u][j], dw);
+            // lane holds dWt[tap = 4 kq + r][sub-pixel = li]; softmax backward over the 9 taps of this sub-pixel
+            float dot = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dot += wv[u][r] * dw[r];
+            dot += __shfl_xor(dot, 16, 64);
+            dot += __shfl_xor(dot, 32, 64);
+            float* dep = de + pix[u] * (9 * S2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * kq + r < 9) dep[(4 * kq + r) * S2 + li] = wv[u][r] * (dw[r] - dot);
         }
-        // C layout: lane holds G[tap = 4 kq + r][channel = li]
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * kq + r < 9) Gp[(4 * kq + r) * Cz + li] = g[r];
-        const bool interior = ph >= 1 && ph <= C4_T && pw >= 1 && pw <= C4_T;                 // wave-uniform
-        if (!interior) continue;
-        bsum += dsum;
-        // ---- dWt = Znbr . D^T : A lane (tap li, channels 4 kq + j), B lane (sub-pixel li, channels 4 kq + j) ----
-        f32x4 za = {0.f, 0.f, 0.f, 0.f};
-        if (li < 9) {
-            const int nh = ph + li / 3 - 1, nw = pw + li % 3 - 1;                           // neighbour inside the halo region
-            za = *reinterpret_cast<const f32x4*>(&zt[(nh * C4_HALO + nw) * Cz + 4 * kq]);    // zeros outside the image
-        }
-        const f32x4 db = *reinterpret_cast<const f32x4*>(drow + (li >> 2) * hstride + (li & 3) * Cz + 4 * kq);
-        f32x4 dw = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dw = carafe_mfma4(za[j], db[j], dw);
-        // lane holds dWt[tap = 4 kq + r][sub-pixel = li]; softmax backward over the 9 taps of this sub-pixel
-        float wv[4], dot = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            wv[r] = 4 * kq + r < 9 ? wp[(4 * kq + r) * S2 + li] : 0.f;
-            dot += wv[r] * dw[r];
-        }
-        dot += __shfl_xor(dot, 16, 64);
-        dot += __shfl_xor(dot, 32, 64);
-        float* dep = de + pix * (9 * S2);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * kq + r < 9) dep[(4 * kq + r) * S2 + li] = wv[r] * (dw[r] - dot);
     }
     bsum += __shfl_xor(bsum, 16, 64);
     bsum += __shfl_xor(bsum, 32, 64);
     if (lane < Cz) bred[wave][lane] = bsum;
     __syncthreads();
-    if (tid < Cz && dbias_part) dbias_part[(long)blockIdx.x * Cz + tid] = bred[0][tid] + bred[1][tid] + bred[2][tid] + bred[3][tid];
+    if (tid < Cz && dbias_part) {
+        float t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < C4_WAVES; ++k) t2 += bred[k][tid];
+        dbias_part[(long)blockIdx.x * Cz + tid] = t2;
+    }
 
     // ---- dz of the 64 interior pixels: 4 lanes x 16 B per pixel ----
-    {
+    if (tid < 256) {
         const int n = tid >> 2, c4 = tid & 3;
         const int ph = 1 + n / C4_T, pw = 1 + n % C4_T;
         const int h = h0 + ph, w = w0 + pw;
@@ -356,7 +386,7 @@ int cswin_carafe_bwd(const float* dout, const float* z, const float* wt_save, fl
     static const bool no_fused = getenv("CSWIN_CARAFE_GENERIC") != nullptr;                  // tuning aid
     if (carafe4_fused_ok(H, W, Cz, S) && !no_fused) {
         const int tx = W / C4_T, ty = H / C4_T, nblk = B * tx * ty;
-        hipLaunchKernelGGL(carafe4_bwd_fused_kernel, dim3(nblk), dim3(256), 0, st, dout, z, wt_save, de, dz,
+        hipLaunchKernelGGL(carafe4_bwd_fused_kernel, dim3(nblk), dim3(64 * C4_WAVES), 0, st, dout, z, wt_save, de, dz,
                            dbias ? (float*)workspace : nullptr, B, H, W, tx, ty);
         CSWIN_LAUNCH_CHECK();
         if (dbias) {
