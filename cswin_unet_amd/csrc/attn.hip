@@ -554,7 +554,7 @@ __device__ __forceinline__ float oct_sum(float v) {
 //       work of tile qt.  Then dV += LePE^T(dO), dK, dV -> global.
 //   P3  K fragments -> LDS over the dead Q image; dQ^T = K^T dS^T per query tile (one per wave) -> global.
 template <int NT>
-__global__ __launch_bounds__(64 * NT, (NT <= 4 ? 4 : 2)) void attn_bwd2_kernel(AttnParams p) {
+__global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {      // 4 waves per SIMD: <= 128 VGPRs, two workgroups per CU at NT = 7
     constexpr int NP = 16 * NT;
     constexpr int NTHREADS = 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -562,7 +562,8 @@ __global__ __launch_bounds__(64 * NT, (NT <= 4 ? 4 : 2)) void attn_bwd2_kernel(A
     float* QK = smem;                       // [NP][LDT]
     float* Ds = QK + NP * LDT;              // [NP][LDT]
     float* VS = Ds + NP * LDT;              // V [NP][LDT], then dS [NP][S]
-    float* lse_s = VS + NP * (S > LDT ? S : LDT);
+    constexpr int VS_MIN = NP * LDT + NT * 10 * HD;   // V image + the waves' LePE gradient slabs (P1)
+    float* lse_s = VS + (NP * S > VS_MIN ? NP * S : VS_MIN);
     float* del_s = lse_s + NP;
     float* Wl = del_s + NP;                 // [10][HD]
 
@@ -605,13 +606,15 @@ __global__ __launch_bounds__(64 * NT, (NT <= 4 ? 4 : 2)) void attn_bwd2_kernel(A
             dv[it] = *reinterpret_cast<const f32x4*>(dy_b + (long)l * p.C + ch0 + 4 * c4);
         }
     }
-    // P1 walks tokens t = 2 wave + half + 2 NT j (half-wave per token, lane & 31 = channel): its y values, loaded now
-    const int dch = lane & 31;
-    float yt[8];
+    // P1 walks tokens t = 8 wave + (lane >> 3) + 8 NT j, j = 0, 1 (eight lanes per token, lane & 7 = 16-B channel chunk): its
+    // y values, loaded now
+    const int pc4 = lane & 7, ptg = lane >> 3;
+    f32x4 yv[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int t = 2 * wave + (lane >> 5) + 2 * NT * j;
-        yt[j] = (t < N && dch < p.hd) ? y_b[(long)token_of(br, w, p.reso, t) * p.C + ch0 + dch] : 0.f;
+    for (int j = 0; j < 2; ++j) {
+        const int t = 8 * wave + ptg + 8 * NT * j;
+        yv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < N && 4 * pc4 < p.hd) yv[j] = *reinterpret_cast<const f32x4*>(y_b + (long)token_of(br, w, p.reso, t) * p.C + ch0 + 4 * pc4);
     }
     for (int t = tid; t < NP; t += NTHREADS) {
         lse_s[t] = t < N ? lse_b[token_of(br, w, p.reso, t)] : INFINITY;   // +inf -> P = 0 on padded query rows
@@ -645,61 +648,94 @@ __global__ __launch_bounds__(64 * NT, (NT <= 4 ? 4 : 2)) void attn_bwd2_kernel(A
             vf[4 + e] = v1[e];
         }
     }
-    float a[10];                                        // LePE gradient partial of this wave; reduced and stored at the very end
-    {                                                   // so that the barriers below do not wait for global-store acknowledgements
-        float wt[10];
+    // Eight lanes per token, four channels per lane: neighbour index and validity are computed once per 16 B instead of
+    // once per float, the taps are b128 LDS reads, delta is an 8-lane DPP sum.  The wave's [10][32] gradient partial goes
+    // to the part of the VS region that the V image does not use; it is combined over the waves after the barrier.
+    float* slab = VS + NP * LDT;                        // [NT][10][HD]
+    {
+        f32x4 a4[10];
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            a[i] = 0.f;
-            wt[i] = Wl[i * HD + dch];
-        }
+        for (int i = 0; i < 10; ++i) a4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 bias4 = *reinterpret_cast<const f32x4*>(&Wl[9 * HD + 4 * pc4]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int t = 2 * wave + (lane >> 5) + 2 * NT * j;
+        for (int j = 0; j < 2; ++j) {
+            const int t = 8 * wave + ptg + 8 * NT * j;
             const bool tv = t < N;
             const int tc = tv ? t : 0;
-            const float g = tv ? Ds[tc * LDT + dch] : 0.f;
-            const int rr = thin ? 0 : tc / br.W_sp, cc = thin ? 0 : tc - rr * br.W_sp;         // thin stripes: unused
-            float b[9];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) b[i] = 0.f;
-            if (thin) lepe_wgrad_taps<true>(br, VS, rr, cc, tc, dch, g, b);
-            else lepe_wgrad_taps<false>(br, VS, rr, cc, tc, dch, g, b);
-            float lw = 0.f;                             // g * sum_tap W[tap][d] V[nbr][d]
-            if (thin) {                                 // b[0..2] are taps (1, j) or (j, 1)
+            f32x4 g4 = *reinterpret_cast<const f32x4*>(&Ds[tc * LDT + 4 * pc4]);
+            if (!tv) g4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 lw4 = {0.f, 0.f, 0.f, 0.f};           // sum_tap W[tap] o V[nbr]
+            if (thin) {
                 const bool row = br.H_sp == 1;
-                lw = (row ? wt[3] : wt[1]) * b[0] + wt[4] * b[1] + (row ? wt[5] : wt[7]) * b[2];
-                a[0] += b[0];
-                a[1] += b[1];
-                a[2] += b[2];
-            } else {
 #pragma unroll
-                for (int i = 0; i < 9; ++i) {
-                    lw += wt[i] * b[i];
-                    a[i] += b[i];
+                for (int q = 0; q < 3; ++q) {           // a4[q] holds tap (1, q) or (q, 1); expanded below
+                    const int t2 = tc + q - 1;
+                    const bool ok = (unsigned)t2 < (unsigned)N;
+                    f32x4 v4 = *reinterpret_cast<const f32x4*>(&VS[(ok ? t2 : tc) * LDT + 4 * pc4]);
+                    if (!ok) v4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&Wl[(row ? 3 + q : 3 * q + 1) * HD + 4 * pc4]);
+                    a4[q] += g4 * v4;
+                    lw4 += w4 * v4;
                 }
-            }
-            a[9] += g;
-            float part = g * (yt[j] - wt[9]) - lw;
-            part = row16_sum(part);
-            part += __shfl_xor(part, 16, 64);
-            if (tv && dch == 0) del_s[t] = part;
-        }
-        if (thin) {                                             // a[0..2] -> taps (1, j) or (j, 1); the other six are zero
-            const bool row = br.H_sp == 1;
-            const float t0 = a[0], t1 = a[1], t2 = a[2];
-            a[0] = a[2] = a[6] = a[8] = 0.f;
-            a[1] = row ? 0.f : t0;
-            a[3] = row ? t0 : 0.f;
-            a[4] = t1;
-            a[5] = row ? t2 : 0.f;
-            a[7] = row ? 0.f : t2;
-        }
+            } else {
+                const int rr = tc / br.W_sp, cc = tc - rr * br.W_sp;
 #pragma unroll
-        for (int i = 0; i < 10; ++i) a[i] += __shfl_xor(a[i], 32, 64);
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int r2 = rr + ky - 1, c2 = cc + kx - 1;
+                        const bool ok = (unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp;
+                        f32x4 v4 = *reinterpret_cast<const f32x4*>(&VS[(ok ? r2 * br.W_sp + c2 : tc) * LDT + 4 * pc4]);
+                        if (!ok) v4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(&Wl[(ky * 3 + kx) * HD + 4 * pc4]);
+                        a4[ky * 3 + kx] += g4 * v4;
+                        lw4 += w4 * v4;
+                    }
+            }
+            a4[9] += g4;
+            const f32x4 o4 = yv[j] - bias4 - lw4;
+            const float part = oct_sum(g4[0] * o4[0] + g4[1] * o4[1] + g4[2] * o4[2] + g4[3] * o4[3]);
+            if (tv && pc4 == 0) del_s[t] = part;
+        }
+        if (thin) {                                             // a4[0..2] -> taps (1, q) or (q, 1); the other six are zero
+            const bool row = br.H_sp == 1;
+            const f32x4 t0 = a4[0], t1 = a4[1], t2 = a4[2], zero = {0.f, 0.f, 0.f, 0.f};
+            a4[0] = a4[2] = a4[6] = a4[8] = zero;
+            a4[1] = row ? zero : t0;
+            a4[3] = row ? t0 : zero;
+            a4[4] = t1;
+            a4[5] = row ? t2 : zero;
+            a4[7] = row ? zero : t2;
+        }
+        // sum over the eight token slots of the wave (lanes that share lane & 7): rotate by 8 inside the DPP row, then
+        // across the four rows
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = a4[i][e];
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                a4[i][e] = v;
+            }
+        if (lane < 8) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) *reinterpret_cast<f32x4*>(&slab[(wave * 10 + i) * HD + 4 * lane]) = a4[i];
+        }
     }
     ATTN_STAMP(2);
-    __syncthreads();                                    // V image dead: VS becomes the dS image; delta complete
+    __syncthreads();                                    // V image dead; delta and the waves' LePE partials complete
+    float lepe_part[2] = {0.f, 0.f};                    // elements tid, tid + NTHREADS of the workgroup's [10][HD] partial
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + u * NTHREADS;
+        if (i < 10 * HD) {
+#pragma unroll
+            for (int k = 0; k < NT; ++k) lepe_part[u] += slab[k * 10 * HD + i];
+        }
+    }
+    __syncthreads();                                    // VS becomes the dS image
 
     // ---- P2: fused S / dP -> P, dS -> dV^T, dK^T ----
     f32x4 dVt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -798,19 +834,9 @@ __global__ __launch_bounds__(64 * NT, (NT <= 4 ? 4 : 2)) void attn_bwd2_kernel(A
         }
     }
     ATTN_STAMP(5);
-    // LePE gradient partials of the NT waves -> one slab row per workgroup, through the (now dead) K image
-    __syncthreads();
-    if (lane < 32) {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) QK[(wave * 10 + i) * HD + lane] = a[i];
-    }
-    __syncthreads();
-    for (int i = tid; i < 10 * HD; i += NTHREADS) {
-        float sum = 0.f;
-#pragma unroll
-        for (int k = 0; k < NT; ++k) sum += QK[k * 10 * HD + i];
-        store_lepe_partial(p, br, w, 0, i, sum);
-    }
+    for (int u = 0; u < 2; ++u)
+        if (tid + u * NTHREADS < 10 * HD) store_lepe_partial(p, br, w, 0, tid + u * NTHREADS, lepe_part[u]);
     ATTN_STAMP(6);
 }
 
@@ -1232,7 +1258,8 @@ int launch_bwd(const AttnParams& p, int nwg, hipStream_t st) {
 template <int NT>
 int launch_bwd2(const AttnParams& p, int nwg, hipStream_t st) {
     const int NP = 16 * NT, S = p.ds_stride;
-    const size_t lds = (size_t)(2 * NP * LDT + NP * (S > LDT ? S : LDT) + 2 * NP + 10 * HD) * sizeof(float);
+    const int vs_min = NP * LDT + NT * 10 * HD;
+    const size_t lds = (size_t)(2 * NP * LDT + (NP * S > vs_min ? NP * S : vs_min) + 2 * NP + 10 * HD) * sizeof(float);
     static size_t reserved = 0;         // one-time per size: not a stream operation, keep it out of graph captures
     if (lds > 64 * 1024 && lds > reserved) {
         hipError_t e = hipFuncSetAttribute((const void*)attn_bwd2_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
