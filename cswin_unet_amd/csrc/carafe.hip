@@ -73,10 +73,14 @@ __global__ __launch_bounds__(256) void carafe_fwd_kernel(const float* __restrict
 }
 
 // de[b,hw,k*S2+s] = Wt[k] * (dWt[k] - sum_j Wt[j] dWt[j]),  dWt[k] = sum_c dout[pix(s), c] * z[nbr_k, c]
+// dbias_part != NULL (Cz <= 512): the kernel streams over dout anyway, so it also leaves the per-workgroup column sums of dout
+// in dbias_part[block][Cz] (dbias = their sum), which saves the separate column-sum pass over dout.
 template <int S>
 __global__ __launch_bounds__(256) void carafe_bwd_e_kernel(const float* __restrict__ dout, const float* __restrict__ z,
                                                             const float* __restrict__ wt_save, float* __restrict__ de,
-                                                            int B, int H, int W, int Cz) {
+                                                            float* __restrict__ dbias_part, int B, int H, int W, int Cz) {
+    __shared__ float bred[2 * 1024];                 // [chunk][group][4 * lpr]: groups * 4 * lpr = 1024 floats per chunk
+    f32x4 bacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     constexpr int S2 = S * S;
     const int lpr = carafe_lpr(Cz);
     const int groups = 256 / lpr;
@@ -96,8 +100,13 @@ __global__ __launch_bounds__(256) void carafe_bwd_e_kernel(const float* __restri
         float dwt[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) dwt[k] = 0.f;
-        for (int c = 4 * sub; c < Cz; c += 4 * lpr) {
+        int ci = 0;
+        for (int c = 4 * sub; c < Cz; c += 4 * lpr, ++ci) {
             const f32x4 g = *reinterpret_cast<const f32x4*>(dout + orow * Cz + c);
+            if (live && dbias_part) {
+                if (ci == 0) bacc[0] += g;
+                else bacc[1] += g;
+            }
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 const int hh = h + k / 3 - 1, ww = w + k % 3 - 1;
@@ -119,6 +128,20 @@ __global__ __launch_bounds__(256) void carafe_bwd_e_kernel(const float* __restri
             }
 #pragma unroll
             for (int k = 0; k < 9; ++k) de[pix * (9 * S2) + k * S2 + s] = wt[k] * (dwt[k] - dot);
+        }
+    }
+    if (dbias_part) {                                 // column sums of this workgroup's rows of dout
+        const int span = 4 * lpr;                     // channels covered by one chunk
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bred[(q * groups + grp) * span + 4 * sub + e] = bacc[q][e];
+        __syncthreads();
+        for (int c = threadIdx.x; c < Cz; c += 256) {
+            const int q = c / span, cc = c - q * span;
+            float t = 0.f;
+            for (int g2 = 0; g2 < groups; ++g2) t += bred[(q * groups + g2) * span + cc];
+            dbias_part[(long)blockIdx.x * Cz + c] = t;
         }
     }
 }
@@ -370,6 +393,8 @@ static bool carafe4_fused_ok(int H, int W, int Cz, int S) { return S == 4 && Cz 
 
 size_t cswin_carafe_bwd_workspace(int B, int H, int W, int Cz, int S) {
     size_t generic = (size_t)colsum_blocks((long)B * H * W * S * S, Cz) * Cz * sizeof(float);
+    size_t in_e = Cz <= 512 ? (size_t)grid_for((long)B * H * W * S * S, 256 / carafe_lpr(Cz)) * Cz * sizeof(float) : 0;
+    if (in_e > generic) generic = in_e;
     size_t fused = carafe4_fused_ok(H, W, Cz, S) ? (size_t)B * (H / C4_T) * (W / C4_T) * Cz * sizeof(float) : 0;
     return generic > fused ? generic : fused;
 }
@@ -395,15 +420,21 @@ int cswin_carafe_bwd(const float* dout, const float* z, const float* wt_save, fl
         }
         return CSWIN_OK;
     }
+    const bool bias_in_e = dbias && Cz <= 512;        // at most two 16-B chunks per lane: the column sums ride along in bwd_e
+    float* bpart = bias_in_e ? (float*)workspace : nullptr;
+    const int eblk = grid_for(items, groups);
     if (S == 2) {
-        hipLaunchKernelGGL(carafe_bwd_e_kernel<2>, dim3(grid_for(items, groups)), dim3(256), 0, st, dout, z, wt_save, de, B, H, W, Cz);
+        hipLaunchKernelGGL(carafe_bwd_e_kernel<2>, dim3(eblk), dim3(256), 0, st, dout, z, wt_save, de, bpart, B, H, W, Cz);
         hipLaunchKernelGGL(carafe_bwd_z_kernel<2>, dim3(grid_for(pixels, groups)), dim3(256), 0, st, dout, wt_save, dz, B, H, W, Cz);
     } else {
-        hipLaunchKernelGGL(carafe_bwd_e_kernel<4>, dim3(grid_for(items, groups)), dim3(256), 0, st, dout, z, wt_save, de, B, H, W, Cz);
+        hipLaunchKernelGGL(carafe_bwd_e_kernel<4>, dim3(eblk), dim3(256), 0, st, dout, z, wt_save, de, bpart, B, H, W, Cz);
         hipLaunchKernelGGL(carafe_bwd_z_kernel<4>, dim3(grid_for(pixels, groups)), dim3(256), 0, st, dout, wt_save, dz, B, H, W, Cz);
     }
     CSWIN_LAUNCH_CHECK();
-    if (dbias) {
+    if (bias_in_e) {
+        launch_rows_sum((const float*)workspace, dbias, nullptr, 0, Cz, eblk, Cz, st);
+        CSWIN_LAUNCH_CHECK();
+    } else if (dbias) {
         int nblk = colsum_blocks(items, Cz);
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, dout, (float*)workspace, items, Cz);
         launch_rows_sum((const float*)workspace, dbias, nullptr, 0, Cz, nblk, Cz, st);
