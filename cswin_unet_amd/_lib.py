@@ -38,7 +38,7 @@ SIGNATURES = {
     "cswin_conv_tok_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "cswin_conv_tok_bwd_data": (I, [P, P, P, I, I, I, I, I, I, I, I, P]),
     "cswin_conv_tok_bwd_weight_workspace": (SZ, [I, I, I, I, I, I, I, I]),
-    "cswin_conv_tok_bwd_weight": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, I, I, P]),
+    "cswin_conv_tok_bwd_weight": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, I, I, I, P]),
     "cswin_conv_weight_permute": (I, [P, P, P, I, I, I, I, P]),
     "cswin_conv_weight_unpermute": (I, [P, P, I, I, I, I, P]),
     "cswin_nchw_to_tokens": (I, [P, P, I, I, I, I, I, P]),

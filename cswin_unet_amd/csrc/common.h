@@ -113,6 +113,51 @@ __device__ __forceinline__ void rows_sum_block(const cswin_reduce_job& job, long
     }
 }
 
+// Same reduction for a convolution weight gradient whose slab columns are [Cout][k*k][Cin] (the implicit-GEMM order) while
+// the parameter is [Cout][Cin][k][k]: slabs are read along their columns (coalesced), the nn.Conv2d layout is produced by the
+// 4-B stores of the (small) result.  Columns >= n_first are the bias gradient as usual.
+static __global__ __launch_bounds__(256) void rows_sum_conv_kernel(cswin_reduce_job job, int kk, int Cin) {
+    __shared__ float red[RS_G][RS_COLS + 1];
+    cswin_reduce_job j = job;
+    float* out = j.out;
+    // reduce into LDS exactly like rows_sum_block, then remap the store
+    const int c4 = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const long i0 = (long)blockIdx.x * RS_COLS + 4 * c4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (i0 < j.n) {
+        const float* base = j.part + i0;
+        if (j.reserved & 1) {
+            int r = g;
+            for (; r + RS_G < j.rows; r += 2 * RS_G) {
+                s0 += *reinterpret_cast<const f32x4*>(base + (long)r * j.stride);
+                s1 += *reinterpret_cast<const f32x4*>(base + (long)(r + RS_G) * j.stride);
+            }
+            for (; r < j.rows; r += RS_G) s0 += *reinterpret_cast<const f32x4*>(base + (long)r * j.stride);
+        } else {
+            for (int r = g; r < j.rows; r += RS_G)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (i0 + e < j.n) s0[e] += base[(long)r * j.stride + e];
+        }
+    }
+    s0 += s1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[g][4 * c4 + e] = s0[e];
+    __syncthreads();
+    const long i = (long)blockIdx.x * RS_COLS + threadIdx.x;
+    if (threadIdx.x < RS_COLS && i < j.n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < RS_G; ++k) t += red[k][threadIdx.x];
+        if (j.out2 && i >= j.n_first) j.out2[i - j.n_first] = t;
+        else if (i < j.n_first) {
+            const long co = i / ((long)kk * Cin);
+            const int rem = (int)(i - co * kk * Cin), tap = rem / Cin, ci = rem - tap * Cin;
+            out[(co * Cin + ci) * kk + tap] = t;
+        }
+    }
+}
+
 static __global__ __launch_bounds__(256) void rows_sum_kernel(cswin_reduce_job job) {
     __shared__ float red[RS_G][RS_COLS + 1];
     rows_sum_block(job, blockIdx.x, red);

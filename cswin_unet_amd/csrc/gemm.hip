@@ -866,10 +866,10 @@ size_t cswin_conv_tok_bwd_weight_workspace(int B, int H, int W, int Cin, int Cou
     return cswin_linear_bwd_weight_workspace(B * OH * OW, Cout, ks * ks * Cin);
 }
 
-// dw_perm: [Cout][ks*ks][Cin]; dbias: [Cout]
+// dw_perm: [Cout][ks*ks][Cin], or the nn.Conv2d parameter layout [Cout][Cin][ks][ks] when torch_layout != 0; dbias: [Cout]
 int cswin_conv_tok_bwd_weight(const float* dy, const float* x, float* dw_perm, float* dbias, void* workspace,
                               size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ks, int stride, int pad,
-                              void* stream) {
+                              int torch_layout, void* stream) {
     CSWIN_REQUIRE(dy && x && dw_perm, CSWIN_ERR_SHAPE, "conv_tok_bwd_weight: null pointer");
     CSWIN_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0 && aligned16(dy) && aligned16(x), CSWIN_ERR_ALIGN, "conv_tok_bwd_weight: channels %% 4 and 16-B alignment required");
     int OH = (H + 2 * pad - ks) / stride + 1, OW = (W + 2 * pad - ks) / stride + 1;
@@ -890,7 +890,13 @@ int cswin_conv_tok_bwd_weight(const float* dy, const float* x, float* dw_perm, f
     launch_gemm<false, false, 4, EPI_PLAIN, false>(A, Bm, e, Cout, K, M, splits, rps, st);
     CSWIN_LAUNCH_CHECK();
     long n = (long)Cout * K;
-    launch_rows_sum(slab, dw_perm, dbias, n, n + (dbias ? Cout : 0), splits, slab_stride, st);
+    if (torch_layout) {
+        cswin_reduce_job job = {slab, dw_perm, dbias, n, n + (dbias ? Cout : 0), slab_stride, splits, 0};
+        job.reserved = reduce_job_vec_ok(job);
+        hipLaunchKernelGGL(rows_sum_conv_kernel, dim3((unsigned)((job.n + RS_COLS - 1) / RS_COLS)), dim3(256), 0, st, job, ks * ks, Cin);
+    } else {
+        launch_rows_sum(slab, dw_perm, dbias, n, n + (dbias ? Cout : 0), splits, slab_stride, st);
+    }
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }

@@ -443,17 +443,18 @@ class _ConvTokens(Function):
         assert L == H * W and w.shape[1] == Cin
         Cout, ks = w.shape[0], w.shape[2]
         OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
-        wp, _ = _permute_w(w, Cin, False)
+        need_dx = ctx.needs_input_grad[0]
+        wp, wpt = _permute_w(w, Cin, need_dx)       # both weight images in one launch; the transposed one is kept for backward
         y = torch.empty(B, OH * OW, Cout, dtype=torch.float32, device=x.device)
         call("cswin_conv_tok_fwd", ptr(x), ptr(wp), ptr(b), ptr(y), B, H, W, Cin, Cout, ks, stride, pad, stream())
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, w, wpt)
         ctx.meta = (H, W, stride, pad, b is not None)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w, wpt = ctx.saved_tensors
         H, W, stride, pad, has_b = ctx.meta
         dy = dev_f32(dy)
         B, L, Cin = x.shape
@@ -461,18 +462,17 @@ class _ConvTokens(Function):
         st = stream()
         dx = None
         if ctx.needs_input_grad[0]:
-            _, wpt = _permute_w(w, Cin, True)
+            if wpt is None:
+                _, wpt = _permute_w(w, Cin, True)
             dx = torch.empty_like(x)
             call("cswin_conv_tok_bwd_data", ptr(dy), ptr(wpt), ptr(dx), B, H, W, Cin, Cout, ks, stride, pad, st)
         with _side_stream(dy, x):
-            dwp = torch.empty(Cout, ks * ks, Cin, dtype=torch.float32, device=x.device)
+            dw = torch.empty_like(w)                    # written in the parameter layout by the slab reduction itself
             db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_b else None
             nbytes = lib().cswin_conv_tok_bwd_weight_workspace(B, H, W, Cin, Cout, ks, stride, pad)
             ws = _ws(nbytes, x.device)
-            call("cswin_conv_tok_bwd_weight", ptr(dy), ptr(x), ptr(dwp), ptr(db), ptr(ws), nbytes, B, H, W, Cin, Cout, ks,
-                 stride, pad, stream())
-            dw = torch.empty_like(w)
-            call("cswin_conv_weight_unpermute", ptr(dwp), ptr(dw), Cout, Cin, ks, Cin, stream())
+            call("cswin_conv_tok_bwd_weight", ptr(dy), ptr(x), ptr(dw), ptr(db), ptr(ws), nbytes, B, H, W, Cin, Cout, ks,
+                 stride, pad, 1, stream())
         return dx, dw, db, None, None, None, None
 
 
@@ -515,7 +515,7 @@ class _PatchEmbedConv(Function):
         nbytes = lib().cswin_conv_tok_bwd_weight_workspace(B, H, W, cpad, Cout, ks, stride, pad)
         ws = _ws(nbytes, x.device)
         call("cswin_conv_tok_bwd_weight", ptr(dy), ptr(x), ptr(dwp), ptr(db), ptr(ws), nbytes, B, H, W, cpad, Cout, ks, stride,
-             pad, st)
+             pad, 0, st)                                # channel-padded image (3 -> 4): unpermuted separately
         dw = torch.empty_like(w)
         call("cswin_conv_weight_unpermute", ptr(dwp), ptr(dw), Cout, Cin, ks, cpad, st)
         return None, dw, db, None, None

@@ -119,9 +119,11 @@ int cswin_conv_tok_fwd(const float* x, const float* w_perm, const float* bias, f
 int cswin_conv_tok_bwd_data(const float* dy, const float* w_permT, float* dx, int B, int H, int W, int Cin, int Cout,
                             int ks, int stride, int pad, void* stream);
 size_t cswin_conv_tok_bwd_weight_workspace(int B, int H, int W, int Cin, int Cout, int ks, int stride, int pad);
-int cswin_conv_tok_bwd_weight(const float* dy, const float* x, float* dw_perm, float* dbias, void* workspace,
+/* dw: [Cout][ks*ks][Cin] (torch_layout 0, the image cswin_conv_weight_unpermute takes) or directly the nn.Conv2d parameter
+ * layout [Cout][Cin][ks][ks] (torch_layout 1: the slab reduction writes it, no separate unpermute launch) */
+int cswin_conv_tok_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, void* workspace,
                               size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ks, int stride, int pad,
-                              void* stream);
+                              int torch_layout, void* stream);
 /* w [Cout][Cin][ks][ks] -> w_perm [Cout][ks*ks][Cpad] and/or w_permT [ks*ks][Cout][Cpad] (zero padded channels) */
 int cswin_conv_weight_permute(const float* w, float* w_perm, float* w_permT, int Cout, int Cin, int ks, int Cpad,
                               void* stream);
