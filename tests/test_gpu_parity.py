@@ -453,6 +453,14 @@ def test_trainer_rccl_path_single_rank(N, golden):
         assert tr.collectives
         losses = [float(tr.train_step(img, lab)[0]) for _ in range(3)]
         assert np.allclose(losses, g["sgd_losses"], rtol=2e-3), (losses, g["sgd_losses"])
+        # bf16 gradients on the wire (BASELINE configs[2]): convert / all-reduce / convert back per bucket on the RCCL path
+        net2 = _golden_model(N)
+        net2.train()
+        tr2 = DataParallelTrainer(net2, 9, base_lr=0.05, max_iterations=100, group=dist.group.WORLD, force_collectives=True,
+                                  allreduce_dtype=torch.bfloat16)
+        losses2 = [float(tr2.train_step(img, lab)[0]) for _ in range(3)]
+        assert abs(losses2[0] - g["sgd_losses"][0]) < 2e-3 * g["sgd_losses"][0]
+        assert np.allclose(losses2, g["sgd_losses"], rtol=3e-2), (losses2, g["sgd_losses"])
     finally:
         dist.destroy_process_group()
 
