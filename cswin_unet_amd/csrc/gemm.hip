@@ -583,9 +583,6 @@ void launch_gemm(const ASrc& A, const BSrc& B, const Epilogue& epi_in, int M, in
     Epilogue epi = epi_in;
     epi.vec_store = epilogue_vec_ok(epi, N);
     auto blocks = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(N, bn) * splits; };
-    auto waste = [&](int bn) { return (double)cdiv(N, bn) * bn / N; };
-    static const long want = getenv("CSWIN_GEMM_WANT") ? atol(getenv("CSWIN_GEMM_WANT")) : 384;
-    (void)waste; (void)want;
     static const int forced_kw = getenv("CSWIN_GEMM_KW") ? atoi(getenv("CSWIN_GEMM_KW")) : 0;                    // tuning aid
     // Tile choice.  64 x 64 is the most efficient tile (profiles/round1_gemm_bench.txt), but every workgroup of these
     // launches is resident at once and the kernel ends with the most loaded CU: with t tiles the critical CU does
