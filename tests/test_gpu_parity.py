@@ -316,6 +316,35 @@ def test_carafe_vs_golden(N, golden, name, c, cout, r, S, B):
     _run_module_vs_golden(mod, name, (B, r * r, c), (B, S * S * r * r, cout), golden("g4_convs"))
 
 
+@pytest.mark.parametrize("H,S,Cz,B", [(16, 4, 16, 3), (12, 4, 16, 2), (8, 4, 32, 2), (7, 2, 96, 2), (14, 2, 256, 1), (24, 4, 16, 1)])
+def test_carafe_reassembly_paths_vs_closed_form(ops, H, S, Cz, B):
+    """ops.carafe_reassemble forward / backward against the closed form (softmax over the 9 taps, 3x3 neighbourhood gather of z,
+    zero outside the map): H = 16 / 24 with S = 4, Cz = 16 take the fused 8x8-tile MFMA backward, H = 12 (not a multiple of 8)
+    and Cz = 32 the generic kernels, S = 2 with Cz = 96 / 256 the generic kernels with one and two 16-B chunks per lane (the
+    column sums of dout ride along in the de kernel)."""
+    e = det_normal("cr.e", (B, H * H, 9 * S * S))
+    z = det_normal("cr.z", (B, H * H, Cz))
+    bias = det_normal("cr.b", (Cz,), 0.1)
+    dout = det_normal("cr.dout", (B, S * S * H * H, Cz))
+    er, zr, br = (torch.from_numpy(a).requires_grad_() for a in (e, z, bias))
+    wt = torch.softmax(er.view(B, H, H, 9, S * S), dim=3)                                  # (B, H, W, k, s)
+    zp = torch.nn.functional.pad(zr.view(B, H, H, Cz), (0, 0, 1, 1, 1, 1))
+    up = 0
+    for kk in range(9):
+        ky, kx = divmod(kk, 3)
+        up = up + wt[:, :, :, kk, :, None] * zp[:, ky:ky + H, kx:kx + H, None, :]          # (B, H, W, s, C)
+    out_r = up.view(B, H, H, S, S, Cz).permute(0, 1, 3, 2, 4, 5).reshape(B, S * S * H * H, Cz) + br
+    out_r.backward(torch.from_numpy(dout))
+    ed, zd, bd = T(e, True), T(z, True), T(bias, True)
+    out_d = ops.carafe_reassemble(ed, zd, bd, H, H, S)
+    out_d.backward(T(dout))
+    tag = f"carafe_paths.H{H}S{S}C{Cz}"
+    rel_err(out_d, out_r, tag + ".out")
+    rel_err(ed.grad, er.grad, tag + ".de")
+    rel_err(zd.grad, zr.grad, tag + ".dz")
+    rel_err(bd.grad, br.grad, tag + ".dbias")
+
+
 def test_loss_vs_oracle(ops):
     B, C, H = 3, 9, 64
     logits = det_normal("loss.logits", (B, C, H, H), 2.0)
