@@ -14,9 +14,15 @@
 //
 // Backward recomputes S from q,k and the saved row log-sum-exp.  Each wave owns 16
 // keys: dK^T and dV^T accumulate in registers over all query tiles (P / dS accumulator tiles
-// are again direct MFMA B operands), delta = rowsum(P o dP) is reduced through LDS, dS crosses
-// LDS once for dQ, LePE^T(dO) is added to dV, and the depthwise-conv weight/bias gradients are
-// written as per-workgroup partial slabs (reduced deterministically by a second tiny kernel).
+// are again direct MFMA B operands), dS crosses LDS once for dQ, LePE^T(dO) is added to dV, and
+// the depthwise-conv weight/bias gradients are written as per-workgroup partial slabs (a standard
+// cswin_reduce_job, reduced deterministically by rows_sum).  Three variants by window size:
+//   attn_bwd_kernel   N <= 64:  Q, K, V, dO + dS image in LDS (51 KB, three workgroups per CU);
+//                               delta = rowsum(P o dP) reduced through LDS atomics
+//   attn_bwd2_kernel  N <= 112: Q/K aliased, V/dS aliased (79 KB, two workgroups per CU); delta from
+//                               the saved forward output, one fused S/dP/dV/dK loop
+//   attn_delta / attn_bwd_kv / attn_bwd_q / lepe_wgrad   N > 112: two passes, 64 x 64 at a time
+// Head dims 8 / 16 / 24 / 32 share the kernels (tiles zero-padded to HD = 32).
 #include "common.h"
 #include <stdlib.h>
 
