@@ -172,8 +172,9 @@ class _CarafeBase(nn.Module):
 
     def forward(self, x):
         side = _square_side(x.shape[1])
-        e = self.kernel_logits(x, side)
-        z = ops.linear(x, self.out.weight.flatten(1))                 # `out` conv first, at low resolution
+        # `down` (-> reassembly logits) and `out` (applied first, at low resolution) both read x: one node, one input gradient
+        mid, z = ops.linear_pair(x, self.down.weight.flatten(1), self.down.bias, self.out.weight.flatten(1), None)
+        e = ops.conv_tokens(mid, self.encoder.weight, self.encoder.bias, side, side, 1, 1)
         return ops.carafe_reassemble(e, z, self.out.bias, side, side, self.up_factor)
 
 
@@ -338,8 +339,8 @@ class CSWinTransformer(nn.Module):
         b_fused = ops.linear(up.out.bias[None, :], w_head)[0]                  # (ncls,)   = W_head @ b_out
         w_fused = nn.functional.pad(w_fused, (0, 0, 0, cpad - ncls))           # zero rows -> 16-channel tokens
         b_fused = nn.functional.pad(b_fused, (0, cpad - ncls))
-        e = up.kernel_logits(x, side)
-        z = ops.linear(x, w_fused)
+        mid, z = ops.linear_pair(x, up.down.weight.flatten(1), up.down.bias, w_fused, None)
+        e = ops.conv_tokens(mid, up.encoder.weight, up.encoder.bias, side, side, 1, 1)
         tok = ops.carafe_reassemble(e, z, b_fused, side, side, up.up_factor)   # (B, (4 side)^2, cpad)
         return ops.tokens_to_nchw(tok, ncls, up.up_factor * side, up.up_factor * side)
 

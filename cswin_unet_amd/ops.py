@@ -12,7 +12,7 @@ from torch.autograd.function import once_differentiable
 
 from ._lib import ReduceJob, call, dev_f32, lib, ptr, stream
 
-__all__ = ["layer_norm", "linear", "mlp", "stripe_attention", "cswin_block", "conv_tokens", "patch_embed_conv", "carafe_reassemble",
+__all__ = ["layer_norm", "linear", "linear_pair", "mlp", "stripe_attention", "cswin_block", "conv_tokens", "patch_embed_conv", "carafe_reassemble",
            "tokens_to_nchw", "matmul_nn", "ce_dice_loss", "img2windows", "windows2img"]
 
 
@@ -169,6 +169,56 @@ class _Linear(Function):
 def linear(x, w, b=None, x2=None, residual=None, row_scale=None):
     """y = [x | x2] @ w^T + b;  with residual: y = residual + row_scale[sample] * (...)  (DropPath + skip add)."""
     return _Linear.apply(x, w, b, x2, residual, row_scale)
+
+
+class _LinearPair(Function):
+    """Two Linears of the same input (CARAFE: `down` and `out` 1x1 convs of x, cswin_unet.py:240,265).  As two separate
+    autograd nodes their input gradients meet in an aten::add over (B, L, C); here the second data-gradient GEMM adds into
+    the first one's result in its epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x, w1, b1, w2, b2 = (dev_f32(t) for t in (x, w1, b1, w2, b2))
+        K = x.shape[-1]
+        M = x.numel() // K
+        ys = []
+        for w, b in ((w1, b1), (w2, b2)):
+            assert w.shape[1] == K
+            y = torch.empty(x.shape[:-1] + (w.shape[0],), dtype=torch.float32, device=x.device)
+            call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, w.shape[0], K, stream())
+            ys.append(y)
+        ctx.save_for_backward(x, w1, w2)
+        ctx.has_b = (b1 is not None, b2 is not None)
+        return tuple(ys)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy1, dy2):
+        x, w1, w2 = ctx.saved_tensors
+        dy1, dy2 = dev_f32(dy1), dev_f32(dy2)
+        K = x.shape[-1]
+        M = x.numel() // K
+        st = stream()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            call("cswin_linear_bwd_data", ptr(dy1), ptr(w1), ptr(dx), None, 0, None, None, 1, None, M, w1.shape[0], K, st)
+            call("cswin_linear_bwd_data", ptr(dy2), ptr(w2), ptr(dx), None, 0, None, None, 1, ptr(dx), M, w2.shape[0], K, st)
+        grads = []
+        for dy, w, has_b in ((dy1, w1, ctx.has_b[0]), (dy2, w2, ctx.has_b[1])):
+            N = w.shape[0]
+            dw = torch.empty_like(w)
+            db = torch.empty(N, dtype=torch.float32, device=w.device) if has_b else None
+            nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
+            ws = _ws(nbytes, w.device)
+            call("cswin_linear_bwd_weight", ptr(dy), ptr(x), None, 0, None, 1, ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, None, st)
+            grads += [dw, db]
+        return (dx,) + tuple(grads)
+
+
+def linear_pair(x, w1, b1, w2, b2):
+    """(x @ w1^T + b1, x @ w2^T + b2) with one fused input gradient."""
+    return _LinearPair.apply(x, w1, b1, w2, b2)
 
 
 class _Mlp(Function):
