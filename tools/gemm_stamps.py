@@ -39,3 +39,10 @@ print("  realtime (us): first start 0, last start %.2f, first end %.2f, last end
 for x in sorted(set(s[:, 4] & 15)):
     m = (s[:, 4] & 15) == x
     print(f"   xcd {x}: {m.sum()} wgs, start {(r0[m].min()-base)/100:.2f}..{(r0[m].max()-base)/100:.2f}, end {(r1[m].min()-base)/100:.2f}..{(r1[m].max()-base)/100:.2f} us; mean life {(r1[m]-r0[m]).mean()/100:.2f} us")
+
+# how many workgroups are alive at once? (sweep over the 100 MHz realtime stamps)
+ev = np.concatenate([np.stack([r0, np.ones_like(r0)], 1), np.stack([r1, -np.ones_like(r1)], 1)])
+ev = ev[np.argsort(ev[:, 0], kind="stable")]
+alive = np.cumsum(ev[:, 1])
+dur = np.diff(ev[:, 0])
+print("  workgroups alive: max %d, time-average %.0f (of %d launched); per CU %.2f" % (alive.max(), (alive[:-1] * dur).sum() / max(dur.sum(), 1), len(s), (alive[:-1] * dur).sum() / max(dur.sum(), 1) / 256))
