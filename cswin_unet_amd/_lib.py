@@ -34,6 +34,7 @@ SIGNATURES = {
     "cswin_linear_bwd_data": (I, [P, P, P, P, I, P, P, I, P, I, I, I, P]),
     "cswin_linear_bwd_weight_workspace": (SZ, [I, I, I]),
     "cswin_linear_bwd_weight": (I, [P, P, P, I, P, I, P, P, P, SZ, I, I, I, P, P]),
+    "cswin_linear_bwd_weight_batch": (I, [P, I, P, P]),
     "cswin_rows_sum_multi": (I, [P, I, P]),
     "cswin_conv_tok_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "cswin_conv_tok_bwd_data": (I, [P, P, P, I, I, I, I, I, I, I, I, P]),
@@ -54,6 +55,13 @@ SIGNATURES = {
     "cswin_multi_copy": (I, [P, I, P]),
 }
 
+
+
+class WgradDesc(ctypes.Structure):
+    """Mirror of cswin_wgrad_desc (include/cswin_hip.h)."""
+    _fields_ = [("dy", c_void_p), ("x", c_void_p), ("row_scale", c_void_p), ("dw", c_void_p), ("dbias", c_void_p),
+                ("workspace", c_void_p), ("ws_bytes", c_size_t), ("rows_per_sample", c_int), ("M", c_int), ("N", c_int),
+                ("K", c_int), ("reserved", c_int)]
 
 
 class ReduceJob(ctypes.Structure):

@@ -170,6 +170,19 @@ static inline void launch_rows_sum(const float* part, float* out, float* out2, l
     hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((n + RS_COLS - 1) / RS_COLS)), dim3(256), 0, st, job);
 }
 
+extern "C" {
+typedef struct cswin_wgrad_desc {
+    const float* dy;         // (M, N)
+    const float* x;          // (M, K)
+    const float* row_scale;  // per-sample multiplier of dy rows, or NULL
+    float* dw;               // (N, K)
+    float* dbias;            // (N) or NULL
+    void* workspace;         // cswin_linear_bwd_weight_workspace(M, N, K) bytes, 16-B aligned
+    size_t ws_bytes;
+    int rows_per_sample, M, N, K, reserved;
+} cswin_wgrad_desc;
+}
+
 constexpr int CSWIN_MAX_REDUCE_JOBS = 8;
 struct ReduceJobs {
     cswin_reduce_job j[CSWIN_MAX_REDUCE_JOBS];

@@ -287,8 +287,8 @@ __device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[FM
 // small to give every SIMD >= 2 independent MFMA chains (stage-3/4 shapes with long K) this doubles / quadruples the
 // resident waves per workgroup without a global split-K reduction.
 template <int BM, int BN, int BK, int KW, bool A_RC, bool B_RC, int VEC, int EPI, bool SCALE_A, int PREC, class ASrc, class BSrc>
-__global__ __launch_bounds__(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KW) void gemm_kernel(ASrc A, BSrc B, Epilogue epi, int M, int N, int R,
-                                                    int r_per_split, int tiles_m, int tiles_n) {
+__device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Epilogue& epi, int M, int N, int R,
+                                          int r_per_split, int tiles_m, int tiles_n, int bid, int nblk, int stamp_row) {
     // waves of one k-group: 2 x 2 for 64 x 64 (and larger) tiles, 2 x 1 for 64 x 32: the narrow tile
     // exists for launches whose 64 x 64 tile count is a poor multiple of the 256 CUs (every workgroup is resident at once,
     // so the kernel ends with the most loaded CU)
@@ -316,7 +316,6 @@ __global__ __launch_bounds__(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KW) 
     // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so give every XCD a
     // CONTIGUOUS range of logical blocks, ordered [split][m-tile][n-tile]: the blocks that re-read one A row panel
     // (all n-tiles of an m-tile; all tiles of a split) then share one L2 instead of fetching it eight times.
-    const int nblk = gridDim.x, bid = blockIdx.x;
     const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
     const int lb = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int tiles = tiles_m * tiles_n;
@@ -446,12 +445,12 @@ __global__ __launch_bounds__(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KW) 
     float csum = 0.f;   // dbias partial (TN, A row-contiguous image: column tid of the A tile)
     const bool do_colsum = !A_RC && epi.colsum && n0 == 0 && tid < BM;
 
-    if (epi.stamps && tid == 0) { epi.stamps[8L * blockIdx.x + 0] = __builtin_amdgcn_s_memtime(); epi.stamps[8L * blockIdx.x + 4] = __builtin_amdgcn_s_getreg(6164); epi.stamps[8L * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime(); }
+    if (epi.stamps && tid == 0) { epi.stamps[8L * stamp_row + 0] = __builtin_amdgcn_s_memtime(); epi.stamps[8L * stamp_row + 4] = __builtin_amdgcn_s_getreg(6164); epi.stamps[8L * stamp_row + 5] = __builtin_amdgcn_s_memrealtime(); }
     if (r_begin < r_end) {
         fetch(r_begin);
         stash();
         __syncthreads();
-        if (epi.stamps && tid == 0) epi.stamps[8L * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+        if (epi.stamps && tid == 0) epi.stamps[8L * stamp_row + 1] = __builtin_amdgcn_s_memtime();
         for (int r0 = r_begin; r0 < r_end; r0 += BK) {
             const bool more = r0 + BK < r_end;
             if (more) fetch(r0 + BK);
@@ -519,7 +518,7 @@ __global__ __launch_bounds__(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KW) 
         }
     }
 
-    if (epi.stamps && tid == 0) epi.stamps[8L * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+    if (epi.stamps && tid == 0) epi.stamps[8L * stamp_row + 2] = __builtin_amdgcn_s_memtime();
     if (KW > 1) {
         // sum the wave groups' accumulators (native C/D layout, lane-contiguous LDS patches, binary tree)
         static_assert(KW == 1 || (KW / 2) * NW * FM * FN * 16 * 64 <= LDS_FLOATS, "LDS too small for the k-group reduction");
@@ -552,8 +551,36 @@ __global__ __launch_bounds__(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KW) 
     Epilogue e = epi;
     e.C += (long)split * e.split_stride;
     run_epilogue<EPI, FM, FN>(e, acc, M, N, m0 + wm0, n0 + wn0, lane, lds + wave * EP_WAVE_FLOATS, e.vec_store != 0);
-    if (epi.stamps && tid == 0) { epi.stamps[8L * blockIdx.x + 3] = __builtin_amdgcn_s_memtime(); epi.stamps[8L * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime(); }
+    if (epi.stamps && tid == 0) { epi.stamps[8L * stamp_row + 3] = __builtin_amdgcn_s_memtime(); epi.stamps[8L * stamp_row + 6] = __builtin_amdgcn_s_memrealtime(); }
     if (do_colsum && m0 + tid < M) epi.colsum[(long)split * epi.colsum_stride + m0 + tid] = csum;
+}
+
+template <int BM, int BN, int BK, int KW, bool A_RC, bool B_RC, int VEC, int EPI, bool SCALE_A, int PREC, class ASrc, class BSrc>
+__global__ __launch_bounds__(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KW) void gemm_kernel(ASrc A, BSrc B, Epilogue epi, int M, int N, int R,
+                                                    int r_per_split, int tiles_m, int tiles_n) {
+    gemm_body<BM, BN, BK, KW, A_RC, B_RC, VEC, EPI, SCALE_A, PREC, ASrc, BSrc>(A, B, epi, M, N, R, r_per_split, tiles_m, tiles_n,
+                                                                              (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.x);
+}
+
+// Up to four independent weight-gradient problems (the four Linears of a CSWinBlock: same kernel configuration, operands all
+// alive at the end of the block's backward) in ONE launch: an empty launch costs ~3 us in-stream, and the four grids' tails
+// fill each other.  Each problem keeps its own XCD-aware block order inside its block range.
+constexpr int WGRAD_BATCH = 4;
+struct WgradBatch {
+    PlainSrc A[WGRAD_BATCH], B[WGRAD_BATCH];
+    Epilogue e[WGRAD_BATCH];
+    int M[WGRAD_BATCH], N[WGRAD_BATCH], R[WGRAD_BATCH], rps[WGRAD_BATCH], tm[WGRAD_BATCH], tn[WGRAD_BATCH];
+    int first[WGRAD_BATCH + 1];
+    int n;
+};
+
+template <int PREC>
+__global__ __launch_bounds__(512) void gemm_wgrad_batch_kernel(WgradBatch b) {
+    int p = 0;
+    while (p + 1 < b.n && (int)blockIdx.x >= b.first[p + 1]) ++p;
+    gemm_body<64, 64, 64, 2, false, false, 4, EPI_PLAIN, true, PREC, PlainSrc, PlainSrc>(
+        b.A[p], b.B[p], b.e[p], b.M[p], b.N[p], b.R[p], b.rps[p], b.tm[p], b.tn[p], (int)blockIdx.x - b.first[p],
+        b.first[p + 1] - b.first[p], (int)blockIdx.x);
 }
 
 template <int BM, int BN, int BK, int KW, bool A_RC, bool B_RC, int VEC, int EPI, bool SCALE_A, int PREC, class ASrc, class BSrc>
@@ -635,11 +662,12 @@ Epilogue plain_epilogue(float* C, long ldc) {
 }
 
 // split count for the M-reduction of a weight gradient: enough workgroups to fill the chip
-void choose_split(int M, int out_rows, int out_cols, int* splits, int* r_per_split) {
+void choose_split(int M, int out_rows, int out_cols, int* splits, int* r_per_split, int target_override = 0) {
     // Every workgroup is resident at once and the kernel ends with the most loaded CU, so aim at a workgroup count
     // that is a whole multiple of the 256 CUs (3 per CU): slices need not be multiples of the k-tile (the loaders mask
     // the ragged last tile), only of 8.
-    static const int target = getenv("CSWIN_GEMM_SPLIT_WGS") ? atoi(getenv("CSWIN_GEMM_SPLIT_WGS")) : 768;   // tuning aid
+    static const int target_env = getenv("CSWIN_GEMM_SPLIT_WGS") ? atoi(getenv("CSWIN_GEMM_SPLIT_WGS")) : 768;   // tuning aid
+    const int target = target_override > 0 ? target_override : target_env;
     long tiles = (long)cdiv(out_rows, 64) * cdiv(out_cols, 64);
     int s = (int)(target / tiles);
     if (s < 1) s = 1;
@@ -798,6 +826,61 @@ int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, in
     long n = (long)N * K;
     cswin_reduce_job job = {slab, dw, dbias, n, n + (dbias ? N : 0), slab_stride, splits, 0};
     reduce_now_or_defer(job, deferred, st);
+    CSWIN_LAUNCH_CHECK();
+    return CSWIN_OK;
+}
+
+// n (<= 4) weight gradients without concat sources in one launch (see gemm_wgrad_batch_kernel); deferred[i] receives problem
+// i's slab reduction (run them with cswin_rows_sum_multi).  Falls back to separate launches when a problem is not 16-B
+// aligned / a multiple of 4 in N and K.
+int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferred, void* stream) {
+    CSWIN_REQUIRE(d && deferred && n >= 1 && n <= WGRAD_BATCH, CSWIN_ERR_SHAPE, "linear_bwd_weight_batch: 1..%d problems and their deferred slots", WGRAD_BATCH);
+    bool fast = true;
+    for (int i = 0; i < n; ++i) {
+        CSWIN_REQUIRE(d[i].dy && d[i].x && d[i].dw && d[i].M > 0 && d[i].N > 0 && d[i].K > 0, CSWIN_ERR_SHAPE, "linear_bwd_weight_batch: bad problem %d", i);
+        CSWIN_REQUIRE(!d[i].row_scale || d[i].rows_per_sample > 0, CSWIN_ERR_SHAPE, "linear_bwd_weight_batch: rows_per_sample must be > 0");
+        size_t need = cswin_linear_bwd_weight_workspace(d[i].M, d[i].N, d[i].K);
+        CSWIN_REQUIRE(d[i].workspace && d[i].ws_bytes >= need, CSWIN_ERR_WORKSPACE, "linear_bwd_weight_batch: workspace %zu < %zu", d[i].ws_bytes, need);
+        fast = fast && d[i].N % 4 == 0 && d[i].K % 4 == 0 && aligned16(d[i].dy) && aligned16(d[i].x) && aligned16(d[i].workspace);
+    }
+    if (!fast) {
+        for (int i = 0; i < n; ++i) {
+            int rc = cswin_linear_bwd_weight(d[i].dy, d[i].x, nullptr, 0, d[i].row_scale, d[i].rows_per_sample, d[i].dw, d[i].dbias,
+                                             d[i].workspace, d[i].ws_bytes, d[i].M, d[i].N, d[i].K, &deferred[i], stream);
+            if (rc) return rc;
+        }
+        return CSWIN_OK;
+    }
+    WgradBatch b = {};
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const int M = d[i].M, N = d[i].N, K = d[i].K;
+        int splits, rps;
+        // 256 workgroups per problem: the four problems together are exactly 4 per CU (measured optimum: 192 / 256 / 320 per
+        // problem -> 13.80 / 13.55 / 14.09 ms per step), and a quarter of the slab traffic of the stand-alone launches
+        static const int batch_target = getenv("CSWIN_GEMM_BATCH_WGS") ? atoi(getenv("CSWIN_GEMM_BATCH_WGS")) : 256;   // tuning aid
+        choose_split(M, N, K, &splits, &rps, batch_target);
+        float* slab = (float*)d[i].workspace;
+        const long slab_stride = (long)N * K + N;
+        Epilogue e = plain_epilogue(slab, K);
+        e.split_stride = slab_stride;
+        e.colsum = d[i].dbias ? slab + (long)N * K : nullptr;
+        e.colsum_stride = (int)slab_stride;
+        e.vec_store = epilogue_vec_ok(e, K);
+        b.A[i] = PlainSrc{d[i].dy, N, M, N, d[i].row_scale, d[i].row_scale ? d[i].rows_per_sample : 1};   // S(i = m (reduction), j = n)
+        b.B[i] = PlainSrc{d[i].x, K, M, K, nullptr, 1};
+        b.e[i] = e;
+        b.M[i] = N; b.N[i] = K; b.R[i] = M; b.rps[i] = rps;
+        b.tm[i] = cdiv(N, 64); b.tn[i] = cdiv(K, 64);
+        b.first[i] = blocks;
+        blocks += b.tm[i] * b.tn[i] * splits;
+        const long nk = (long)N * K;
+        deferred[i] = cswin_reduce_job{slab, d[i].dw, d[i].dbias, nk, nk + (d[i].dbias ? N : 0), slab_stride, splits, 0};
+    }
+    b.first[n] = blocks;
+    b.n = n;
+    if (g_matmul_precision == 1) hipLaunchKernelGGL(gemm_wgrad_batch_kernel<1>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, b);
+    else hipLaunchKernelGGL(gemm_wgrad_batch_kernel<0>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, b);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }

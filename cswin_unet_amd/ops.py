@@ -10,7 +10,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from ._lib import ReduceJob, call, dev_f32, lib, ptr, stream
+from ._lib import ReduceJob, WgradDesc, call, dev_f32, lib, ptr, stream
 
 __all__ = ["layer_norm", "linear", "linear_pair", "mlp", "stripe_attention", "cswin_block", "conv_tokens", "patch_embed_conv", "carafe_reassemble",
            "tokens_to_nchw", "matmul_nn", "ce_dice_loss", "img2windows", "windows2img"]
@@ -427,12 +427,19 @@ class _CSWinBlock(Function):
         # ---- MLP branch ----
         dpre = torch.empty_like(pre)
         call("cswin_linear_bwd_data", ptr(dy), ptr(w2), ptr(dpre), None, 0, ptr(pre), ptr(rs2), L, None, M, C, Hd, st)
+        # the four weight gradients are off the critical path: they run as ONE batched launch once all operands exist
+        wg = (WgradDesc * 4)()
+
+        def defer_wgrad(slot, dy_, x_, rs_, dw_, db_, wsi, N_, K_):
+            wg[slot].dy, wg[slot].x, wg[slot].row_scale = dy_.data_ptr(), x_.data_ptr(), (rs_.data_ptr() if rs_ is not None else None)
+            wg[slot].dw, wg[slot].dbias = dw_.data_ptr(), (db_.data_ptr() if db_ is not None else None)
+            wg[slot].workspace, wg[slot].ws_bytes = wsp[wsi].value, sizes[wsi]
+            wg[slot].rows_per_sample, wg[slot].M, wg[slot].N, wg[slot].K = L, M, N_, K_
+
         dw2, db2 = torch.empty_like(w2), E(C)
-        call("cswin_linear_bwd_weight", ptr(dy), ptr(act), None, 0, ptr(rs2), L, ptr(dw2), ptr(db2), wsp[0], sizes[0], M, C, Hd,
-             J(0), st)
+        defer_wgrad(0, dy, act, rs2, dw2, db2, 0, C, Hd)
         dw1, db1 = torch.empty_like(w1), E(Hd)
-        call("cswin_linear_bwd_weight", ptr(dpre), ptr(h2), None, 0, None, 1, ptr(dw1), ptr(db1), wsp[1], sizes[1], M, Hd, C,
-             J(1), st)
+        defer_wgrad(1, dpre, h2, None, dw1, db1, 1, Hd, C)
         dh2 = torch.empty_like(x)
         call("cswin_linear_bwd_data", ptr(dpre), ptr(w1), ptr(dh2), None, 0, None, None, 1, None, M, Hd, C, st)
         dx1, dg2, dbt2 = torch.empty_like(x), E(C), E(C)
@@ -442,8 +449,7 @@ class _CSWinBlock(Function):
         datt = dh2                                                     # reuse
         call("cswin_linear_bwd_data", ptr(dx1), ptr(wp), ptr(datt), None, 0, None, ptr(rs1), L, None, M, C, C, st)
         dwp, dbp = torch.empty_like(wp), E(C)
-        call("cswin_linear_bwd_weight", ptr(dx1), ptr(att), None, 0, ptr(rs1), L, ptr(dwp), ptr(dbp), wsp[3], sizes[3], M, C, C,
-             J(3), st)
+        defer_wgrad(2, dx1, att, rs1, dwp, dbp, 3, C, C)
         dqkv = torch.empty_like(qkv)
         dlw = [torch.empty_like(t) for t in lw]
         dlb = [E(t.shape[0]) for t in lw]
@@ -454,8 +460,11 @@ class _CSWinBlock(Function):
              _ptr_array(dlw), _ptr_array(dlb), ptr(aws), naw, B, reso, C, nb, ha, ia, split, scale, J(6), st)
         dwqkv = torch.empty_like(wqkv)
         dbqkv = E(3 * C) if has_qkv_bias else None
-        call("cswin_linear_bwd_weight", ptr(dqkv), ptr(h1), None, 0, None, 1, ptr(dwqkv), ptr(dbqkv), wsp[4], sizes[4], M, 3 * C, C,
-             J(4), st)
+        defer_wgrad(3, dqkv, h1, None, dwqkv, dbqkv, 4, 3 * C, C)
+        wjobs = (ReduceJob * 4)()
+        call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(wjobs, ctypes.c_void_p), st)
+        for slot, ji in enumerate((0, 1, 3, 4)):
+            jobs[ji] = wjobs[slot]
         dh1 = datt                                                     # reuse again
         call("cswin_linear_bwd_data", ptr(dqkv), ptr(wqkv), ptr(dh1), None, 0, None, None, 1, None, M, 3 * C, C, st)
         dx, dg1, dbt1 = torch.empty_like(x), E(C), E(C)

@@ -107,6 +107,20 @@ size_t cswin_linear_bwd_weight_workspace(int M, int N, int K);
 int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, int k_split, const float* row_scale,
                             int rows_per_sample, float* dw, float* dbias, void* workspace, size_t ws_bytes, int M,
                             int N, int K, cswin_reduce_job* deferred, void* stream);
+/* One problem of cswin_linear_bwd_weight_batch: dw (N, K) = (row_scale * dy)^T @ x, dbias (N) = column sums of dy (or NULL). */
+typedef struct cswin_wgrad_desc {
+    const float* dy;         /* (M, N) */
+    const float* x;          /* (M, K) */
+    const float* row_scale;  /* per-sample multiplier of the dy rows, or NULL */
+    float* dw;               /* (N, K) */
+    float* dbias;            /* (N) or NULL */
+    void* workspace;         /* cswin_linear_bwd_weight_workspace(M, N, K) bytes */
+    size_t ws_bytes;
+    int rows_per_sample, M, N, K, reserved;
+} cswin_wgrad_desc;
+/* Up to 4 independent weight gradients (the four nn.Linear of a CSWinBlock, cswin_unet.py:125,134,17-19) in ONE launch;
+ * deferred[0..n) receive their slab reductions (required: run them with cswin_rows_sum_multi). */
+int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* problems, int n, cswin_reduce_job* deferred, void* stream);
 /* jobs: host array of 1..8 pending reductions (the workspaces they point into must still be alive) */
 int cswin_rows_sum_multi(const cswin_reduce_job* jobs, int njobs, void* stream);
 
