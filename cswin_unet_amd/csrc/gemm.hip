@@ -781,9 +781,11 @@ int cswin_linear_bwd_data(const float* dy, const float* w, float* dx, float* dx2
 }
 
 size_t cswin_linear_bwd_weight_workspace(int M, int N, int K) {
-    int splits, rps;
-    choose_split(M, N, K, &splits, &rps);
-    return (size_t)splits * ((size_t)N * K + N) * sizeof(float);
+    // covers the stand-alone split policy and the batched one (up to 1024 workgroups for a single problem)
+    int s0, s1, rps;
+    choose_split(M, N, K, &s0, &rps);
+    choose_split(M, N, K, &s1, &rps, 1024);
+    return (size_t)(s0 > s1 ? s0 : s1) * ((size_t)N * K + N) * sizeof(float);
 }
 
 // dw[N,K] = (row_scale . dy)^T @ [x | x2];  dbias[N] = colsum(row_scale . dy)
@@ -856,9 +858,10 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
     for (int i = 0; i < n; ++i) {
         const int M = d[i].M, N = d[i].N, K = d[i].K;
         int splits, rps;
-        // 256 workgroups per problem: the four problems together are exactly 4 per CU (measured optimum: 192 / 256 / 320 per
-        // problem -> 13.80 / 13.55 / 14.09 ms per step), and a quarter of the slab traffic of the stand-alone launches
-        static const int batch_target = getenv("CSWIN_GEMM_BATCH_WGS") ? atoi(getenv("CSWIN_GEMM_BATCH_WGS")) : 256;   // tuning aid
+        // 1024 workgroups per launch, i.e. exactly 4 per CU, shared by the problems (measured with four problems: 192 / 256 /
+        // 320 per problem -> 13.80 / 13.55 / 14.09 ms per step); a quarter of the slab traffic of four stand-alone launches
+        static const int batch_env = getenv("CSWIN_GEMM_BATCH_WGS") ? atoi(getenv("CSWIN_GEMM_BATCH_WGS")) : 0;   // tuning aid
+        const int batch_target = batch_env > 0 ? batch_env : 1024 / n;
         choose_split(M, N, K, &splits, &rps, batch_target);
         float* slab = (float*)d[i].workspace;
         const long slab_stride = (long)N * K + N;

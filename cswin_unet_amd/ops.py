@@ -204,15 +204,21 @@ class _LinearPair(Function):
             dx = torch.empty_like(x)
             call("cswin_linear_bwd_data", ptr(dy1), ptr(w1), ptr(dx), None, 0, None, None, 1, None, M, w1.shape[0], K, st)
             call("cswin_linear_bwd_data", ptr(dy2), ptr(w2), ptr(dx), None, 0, None, None, 1, ptr(dx), M, w2.shape[0], K, st)
-        grads = []
-        for dy, w, has_b in ((dy1, w1, ctx.has_b[0]), (dy2, w2, ctx.has_b[1])):
+        grads, keep = [], []
+        wg, jobs = (WgradDesc * 2)(), (ReduceJob * 2)()
+        for i, (dy, w, has_b) in enumerate(((dy1, w1, ctx.has_b[0]), (dy2, w2, ctx.has_b[1]))):
             N = w.shape[0]
             dw = torch.empty_like(w)
             db = torch.empty(N, dtype=torch.float32, device=w.device) if has_b else None
             nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
             ws = _ws(nbytes, w.device)
-            call("cswin_linear_bwd_weight", ptr(dy), ptr(x), None, 0, None, 1, ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, None, st)
+            keep.append(ws)
+            wg[i].dy, wg[i].x, wg[i].row_scale, wg[i].dw = dy.data_ptr(), x.data_ptr(), None, dw.data_ptr()
+            wg[i].dbias, wg[i].workspace, wg[i].ws_bytes = (db.data_ptr() if has_b else None), ws.data_ptr(), nbytes
+            wg[i].rows_per_sample, wg[i].M, wg[i].N, wg[i].K = 1, M, N, K
             grads += [dw, db]
+        call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 2, ctypes.cast(jobs, ctypes.c_void_p), st)
+        call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), 2, st)
         return (dx,) + tuple(grads)
 
 
