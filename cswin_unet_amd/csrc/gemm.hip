@@ -566,19 +566,33 @@ __global__ __launch_bounds__(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KW) 
 // alive at the end of the block's backward) in ONE launch: an empty launch costs ~3 us in-stream, and the four grids' tails
 // fill each other.  Each problem keeps its own XCD-aware block order inside its block range.
 constexpr int WGRAD_BATCH = 4;
-struct WgradBatch {
-    PlainSrc A[WGRAD_BATCH], B[WGRAD_BATCH];
+template <class ASrc, class BSrc>
+struct GemmBatch {
+    ASrc A[WGRAD_BATCH];
+    BSrc B[WGRAD_BATCH];
     Epilogue e[WGRAD_BATCH];
     int M[WGRAD_BATCH], N[WGRAD_BATCH], R[WGRAD_BATCH], rps[WGRAD_BATCH], tm[WGRAD_BATCH], tn[WGRAD_BATCH];
     int first[WGRAD_BATCH + 1];
     int n;
 };
+typedef GemmBatch<PlainSrc, PlainSrc> WgradBatch;
 
 template <int PREC>
 __global__ __launch_bounds__(512) void gemm_wgrad_batch_kernel(WgradBatch b) {
     int p = 0;
     while (p + 1 < b.n && (int)blockIdx.x >= b.first[p + 1]) ++p;
     gemm_body<64, 64, 64, 2, false, false, 4, EPI_PLAIN, true, PREC, PlainSrc, PlainSrc>(
+        b.A[p], b.B[p], b.e[p], b.M[p], b.N[p], b.R[p], b.rps[p], b.tm[p], b.tn[p], (int)blockIdx.x - b.first[p],
+        b.first[p + 1] - b.first[p], (int)blockIdx.x);
+}
+
+// The four parity classes of a stride-2 3x3 convolution's data gradient (ConvTS2Src) are independent GEMMs over a quarter of
+// the pixels each: alone they fill 1.1 - 1.2 workgroups per CU (the launch ends with the CUs that got two); together 4.6.
+template <int KW, int PREC>
+__global__ __launch_bounds__(256 * KW) void gemm_conv_s2_dgrad_batch_kernel(GemmBatch<ConvTS2Src, TapRowsSrc> b) {
+    int p = 0;
+    while (p + 1 < b.n && (int)blockIdx.x >= b.first[p + 1]) ++p;
+    gemm_body<64, 64, (KW == 1 ? 32 : 64), KW, true, false, 4, EPI_PLAIN, false, PREC, ConvTS2Src, TapRowsSrc>(
         b.A[p], b.B[p], b.e[p], b.M[p], b.N[p], b.R[p], b.rps[p], b.tm[p], b.tn[p], (int)blockIdx.x - b.first[p],
         b.first[p + 1] - b.first[p], (int)blockIdx.x);
 }
@@ -912,7 +926,10 @@ int cswin_conv_tok_bwd_data(const float* dy, const float* w_permT, float* dx, in
     CSWIN_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0 && aligned16(dy) && aligned16(w_permT), CSWIN_ERR_ALIGN, "conv_tok_bwd_data: channels %% 4 and 16-B alignment required");
     int OH = (H + 2 * pad - ks) / stride + 1, OW = (W + 2 * pad - ks) / stride + 1;
     if (ks == 3 && stride == 2 && pad == 1) {
-        // four parity classes, each a dense GEMM over only the taps that reach it (Merge_Block.conv, cswin_unet.py:208)
+        // four parity classes, each a dense GEMM over only the taps that reach it (Merge_Block.conv, cswin_unet.py:208),
+        // launched together (gemm_conv_s2_dgrad_batch_kernel)
+        GemmBatch<ConvTS2Src, TapRowsSrc> b = {};
+        int blocks = 0, n = 0, rmax = 0;
         for (int py = 0; py < 2; ++py)
             for (int px = 0; px < 2; ++px) {
                 const int H2 = (H - py + 1) / 2, W2 = (W - px + 1) / 2;
@@ -926,12 +943,35 @@ int cswin_conv_tok_bwd_data(const float* dy, const float* w_permT, float* dx, in
                         ++nt;
                     }
                 const int Mc = B * H2 * W2, Rc = nt * Cout;
-                ConvTS2Src A = {dy, B, H, W, Cout, OH, OW, py, px, H2, W2, kys, kxs, Mc, Rc};
-                TapRowsSrc Bm = {w_permT, Cout, Cin, taps, Rc, Cin};
+                b.A[n] = ConvTS2Src{dy, B, H, W, Cout, OH, OW, py, px, H2, W2, kys, kxs, Mc, Rc};
+                b.B[n] = TapRowsSrc{w_permT, Cout, Cin, taps, Rc, Cin};
                 Epilogue e = plain_epilogue(dx, Cin);
                 e.rm_on = 1; e.rm_H = H; e.rm_W = W; e.rm_H2 = H2; e.rm_W2 = W2; e.rm_py = py; e.rm_px = px;
-                launch_gemm<true, false, 4, EPI_PLAIN, false>(A, Bm, e, Mc, Cin, Rc, 1, cdiv(Rc, BKMAX) * BKMAX, (hipStream_t)stream);
+                e.vec_store = epilogue_vec_ok(e, Cin);
+                b.e[n] = e;
+                b.M[n] = Mc; b.N[n] = Cin; b.R[n] = Rc; b.rps[n] = cdiv(Rc, BKMAX) * BKMAX;
+                b.tm[n] = cdiv(Mc, 64); b.tn[n] = cdiv(Cin, 64);
+                b.first[n] = blocks;
+                blocks += b.tm[n] * b.tn[n];
+                rmax = Rc > rmax ? Rc : rmax;
+                ++n;
             }
+        if (n > 0) {
+            b.first[n] = blocks;
+            b.n = n;
+            hipStream_t st = (hipStream_t)stream;
+            // few workgroups and a long reduction: split each k-tile over wave groups (same rule as launch_gemm)
+            const int kw = (blocks < 320 && rmax >= 512) ? 4 : ((blocks < 640 && rmax >= 256) ? 2 : 1);
+            if (g_matmul_precision == 1) {
+                hipLaunchKernelGGL((gemm_conv_s2_dgrad_batch_kernel<2, 1>), dim3(blocks), dim3(512), 0, st, b);
+            } else if (kw == 4) {
+                hipLaunchKernelGGL((gemm_conv_s2_dgrad_batch_kernel<4, 0>), dim3(blocks), dim3(1024), 0, st, b);
+            } else if (kw == 2) {
+                hipLaunchKernelGGL((gemm_conv_s2_dgrad_batch_kernel<2, 0>), dim3(blocks), dim3(512), 0, st, b);
+            } else {
+                hipLaunchKernelGGL((gemm_conv_s2_dgrad_batch_kernel<1, 0>), dim3(blocks), dim3(256), 0, st, b);
+            }
+        }
         CSWIN_LAUNCH_CHECK();
         return CSWIN_OK;
     }
