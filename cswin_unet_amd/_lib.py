@@ -42,6 +42,7 @@ SIGNATURES = {
     "cswin_conv_tok_bwd_weight": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, I, I, I, P]),
     "cswin_conv_weight_permute": (I, [P, P, P, I, I, I, I, P]),
     "cswin_conv_weight_unpermute": (I, [P, P, I, I, I, I, P]),
+    "cswin_conv_weight_flipT": (I, [P, P, I, I, I, P]),
     "cswin_nchw_to_tokens": (I, [P, P, I, I, I, I, I, P]),
     "cswin_tokens_to_nchw": (I, [P, P, I, I, I, I, I, P]),
     "cswin_carafe_fwd": (I, [P, P, P, P, P, I, I, I, I, I, P]),

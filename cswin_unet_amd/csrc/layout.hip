@@ -63,6 +63,18 @@ __global__ void conv_w_unpermute_kernel(const float* __restrict__ dwp, float* __
     }
 }
 
+// wf[ci][tap'][co] = w[co][ci][kk - 1 - tap']: the weight image with which the DATA gradient of a stride-1 "same" convolution
+// is itself a forward convolution of dy (Cout -> Cin channels, taps mirrored), i.e. runs on the forward implicit-GEMM kernel
+__global__ void conv_w_flipT_kernel(const float* __restrict__ w, float* __restrict__ wf, int Cout, int Cin, int kk) {
+    const long total = (long)Cin * kk * Cout;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(o % Cout);
+        const int tap = (int)((o / Cout) % kk);
+        const int ci = (int)(o / ((long)Cout * kk));
+        wf[o] = w[((long)co * Cin + ci) * kk + (kk - 1 - tap)];
+    }
+}
+
 int grid1d(long total) {
     long b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -91,6 +103,13 @@ int cswin_tokens_to_nchw(const float* x, float* y, int B, int C, int H, int W, i
 int cswin_conv_weight_permute(const float* w, float* w_perm, float* w_permT, int Cout, int Cin, int ks, int Cpad, void* stream) {
     CSWIN_REQUIRE(w && (w_perm || w_permT) && Cout > 0 && Cin > 0 && ks > 0 && Cpad >= Cin, CSWIN_ERR_SHAPE, "conv_weight_permute: bad arguments");
     hipLaunchKernelGGL(conv_w_permute_kernel, dim3(grid1d((long)Cout * ks * ks * Cpad)), dim3(256), 0, (hipStream_t)stream, w, w_perm, w_permT, Cout, Cin, ks * ks, Cpad);
+    CSWIN_LAUNCH_CHECK();
+    return CSWIN_OK;
+}
+
+int cswin_conv_weight_flipT(const float* w, float* wf, int Cout, int Cin, int ks, void* stream) {
+    CSWIN_REQUIRE(w && wf && Cout > 0 && Cin > 0 && ks > 0, CSWIN_ERR_SHAPE, "conv_weight_flipT: bad arguments");
+    hipLaunchKernelGGL(conv_w_flipT_kernel, dim3(grid1d((long)Cout * Cin * ks * ks)), dim3(256), 0, (hipStream_t)stream, w, wf, Cout, Cin, ks * ks);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }

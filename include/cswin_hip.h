@@ -142,6 +142,9 @@ int cswin_conv_tok_bwd_weight(const float* dy, const float* x, float* dw, float*
 int cswin_conv_weight_permute(const float* w, float* w_perm, float* w_permT, int Cout, int Cin, int ks, int Cpad,
                               void* stream);
 int cswin_conv_weight_unpermute(const float* dw_perm, float* dw, int Cout, int Cin, int ks, int Cpad, void* stream);
+/* w [Cout][Cin][ks][ks] -> wf [Cin][ks*ks (mirrored)][Cout]: with it the data gradient of a stride-1, pad = ks/2 convolution is
+ * cswin_conv_tok_fwd(dy, wf, NULL, dx, B, H, W, Cout, Cin, ks, 1, pad) (CARAFE encoder, cswin_unet.py:228,241) */
+int cswin_conv_weight_flipT(const float* w, float* wf, int Cout, int Cin, int ks, void* stream);
 
 /* ---- layout adapters at the ends of the token pipeline (Rearrange 'b c h w -> b (h w) c', cswin_unet.py:340;
  *      view/permute of up_x4, :540-541) ---- */
