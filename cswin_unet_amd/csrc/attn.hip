@@ -16,12 +16,12 @@
 // keys: dK^T and dV^T accumulate in registers over all query tiles (P / dS accumulator tiles
 // are again direct MFMA B operands), dS crosses LDS once for dQ, LePE^T(dO) is added to dV, and
 // the depthwise-conv weight/bias gradients are written as per-workgroup partial slabs (a standard
-// cswin_reduce_job, reduced deterministically by rows_sum).  Three variants by window size:
-//   attn_bwd_kernel   N <= 64:  Q, K, V, dO + dS image in LDS (51 KB, three workgroups per CU);
-//                               delta = rowsum(P o dP) reduced through LDS atomics
-//   attn_bwd2_kernel  N <= 112: Q/K aliased, V/dS aliased (79 KB, two workgroups per CU); delta from
-//                               the saved forward output, one fused S/dP/dV/dK loop
+// cswin_reduce_job, reduced deterministically by rows_sum).  Two variants by window size:
+//   attn_bwd2_kernel  N <= 112: Q/K aliased, V/dS aliased (36 KB at N = 56, 79 KB at N = 98: four / two workgroups per CU);
+//                               delta from the saved forward output, one fused S/dP/dV/dK loop
 //   attn_delta / attn_bwd_kv / attn_bwd_q / lepe_wgrad   N > 112: two passes, 64 x 64 at a time
+// (An earlier single-kernel variant with separate Q, K, V, dO images and delta = rowsum(P o dP) through LDS atomics was
+// within 2 % of attn_bwd2_kernel on windows of up to 64 tokens and was dropped.)
 // Head dims 8 / 16 / 24 / 32 share the kernels (tiles zero-padded to HD = 32).
 #include "common.h"
 #include <stdlib.h>
@@ -101,8 +101,6 @@ __device__ __forceinline__ void store_lepe_partial(const AttnParams& p, const At
     do {                                                                                                \
         if (p.stamps && threadIdx.x == 0) p.stamps[(long)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); \
     } while (0)
-
-__host__ __device__ __forceinline__ int w_N_rows(const AttnParams& p) { return (p.br[0].H_sp * p.br[0].W_sp + 3) / 4 * 4; }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -322,226 +320,6 @@ __global__ __launch_bounds__(64 * (QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8))) 
 // =====================================================================================
 // backward
 // =====================================================================================
-// sum over the 16 lanes of a DPP row (the lanes that share lane >> 4); every lane of the row gets the total.
-// row_ror:n rotates within a row of 16 lanes: pure VALU, no LDS crossbar (ds_bpermute) round trips.
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
-    return v;
-}
-
-template <int NT>
-__global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
-    constexpr int NP = 16 * NT;
-    constexpr int NTHREADS = 64 * NT;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Qs = smem;                    // [NP][LDT]   (aliased by the LePE-gradient scratch at the end)
-    float* Ks = Qs + NP * LDT;
-    float* Vs = Ks + NP * LDT;
-    float* Ds = Vs + NP * LDT;           // dO
-    const int LDS_S = p.ds_stride;       // dS row stride: >= N, = 4 (mod 8); N = 56 -> 60 lets three workgroups share a CU
-    float* dSs = Ds + NP * LDT;          // [NP q][LDS_S]
-    const int NR = (w_N_rows(p));         // dS rows kept: the real queries, rounded up to 4
-    float* lse_s = dSs + NR * LDS_S;     // [NP]
-    float* del_s = lse_s + NP;           // [NP]
-    float* Wl = del_s + NP;              // [9][32]
-
-    const WgInfo w = decode_wg(p, blockIdx.x);
-    const AttnBranch& br = p.br[w.bi];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, kq = lane >> 4;
-    const int L = p.reso * p.reso, C3 = 3 * p.C;
-    const int ch0 = br.c0 + w.g * p.hd;
-    const int N = w.N;
-    const float* qkv_b = p.qkv + (long)w.b * L * C3;
-    const float* dy_b = p.dy + (long)w.b * L * p.C;
-    float* dqkv_b = p.dqkv + (long)w.b * L * C3;
-    const float* lse_b = p.lse + ((long)w.b * p.heads_total + br.head0 + w.g) * L;
-    const bool thin = br.H_sp == 1 || br.W_sp == 1;       // wave-uniform
-
-    ATTN_STAMP(0);
-    for (int idx = tid; idx < NP * 8; idx += NTHREADS) {
-        const int row = idx >> 3, c4 = idx & 7;
-        f32x4 qv = {0.f, 0.f, 0.f, 0.f}, kv = qv, vv = qv, dv = qv;
-        if (row < N && 4 * c4 < p.hd) {
-            const int l = token_of(br, w, p.reso, row);
-            const float* src = qkv_b + (long)l * C3 + ch0 + 4 * c4;
-            qv = *reinterpret_cast<const f32x4*>(src);
-            kv = *reinterpret_cast<const f32x4*>(src + p.C);
-            vv = *reinterpret_cast<const f32x4*>(src + 2 * p.C);
-            dv = *reinterpret_cast<const f32x4*>(dy_b + (long)l * p.C + ch0 + 4 * c4);
-        }
-        *reinterpret_cast<f32x4*>(&Qs[row * LDT + 4 * c4]) = qv;
-        *reinterpret_cast<f32x4*>(&Ks[row * LDT + 4 * c4]) = kv;
-        *reinterpret_cast<f32x4*>(&Vs[row * LDT + 4 * c4]) = vv;
-        *reinterpret_cast<f32x4*>(&Ds[row * LDT + 4 * c4]) = dv;
-    }
-    for (int t = tid; t < NP; t += NTHREADS) {
-        lse_s[t] = t < N ? lse_b[token_of(br, w, p.reso, t)] : INFINITY;   // +inf -> P = 0 on padded query rows
-        del_s[t] = 0.f;
-    }
-    for (int i = tid; i < 9 * HD; i += NTHREADS) {
-        const int tap = i / HD, ch = i - tap * HD;
-        Wl[i] = ch < p.hd ? br.lepe_w[(ch0 - br.c0 + ch) * 9 + tap] : 0.f;
-    }
-    __syncthreads();
-    ATTN_STAMP(1);
-
-    // ---- this wave's 16 keys: K and V fragments (B operands, key on the lane) ----
-    const int kw = wave;                               // key tile owned by this wave
-    const int tk = 16 * kw + li;                       // this lane's key token
-    float kf[8], vf[8];
-    {
-        const float* kp = &Ks[tk * LDT + 8 * kq];
-        const float* vp = &Vs[tk * LDT + 8 * kq];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            kf[e] = kp[e];
-            vf[e] = vp[e];
-        }
-    }
-    const bool kvalid = tk < N;
-
-    // ---- loop 1: P[q][key] and dP[q][key] for every query tile; delta[q] += sum_key P dP ----
-    f32x4 P[NT], dP[NT];
-#pragma unroll
-    for (int qt = 0; qt < NT; ++qt) {
-        const float* qp = &Qs[(16 * qt + li) * LDT + 8 * kq];
-        const float* dp = &Ds[(16 * qt + li) * LDT + 8 * kq];
-        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, da = sa;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            sa = mfma4(qp[e], kf[e], sa);              // S[q][key] = sum_d Q[q][d] K[key][d]
-            da = mfma4(dp[e], vf[e], da);              // dP[q][key] = sum_d dO[q][d] V[key][d]
-        }
-        const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_s[16 * qt + 4 * kq]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float pv = kvalid ? __expf(sa[r] * p.scale - ls[r]) : 0.f;
-            sa[r] = pv;
-            const float t = row16_sum(pv * da[r]);
-            if (li == 0) atomicAdd(&del_s[16 * qt + 4 * kq + r], t);
-        }
-        P[qt] = sa;
-        dP[qt] = da;
-    }
-    ATTN_STAMP(2);
-    __syncthreads();
-
-    // ---- loop 2: dS = P o (dP - delta); dV^T += dO^T P; dK^T += Q^T dS; dS -> LDS ----
-    f32x4 dVt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    f32x4 dKt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int qt = 0; qt < NT; ++qt) {
-        const f32x4 de = *reinterpret_cast<const f32x4*>(&del_s[16 * qt + 4 * kq]);
-        f32x4 ds;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ds[r] = P[qt][r] * (dP[qt][r] - de[r]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qrow = 16 * qt + 4 * kq + r;
-            const float* dop = &Ds[qrow * LDT + li];
-            const float* qp = &Qs[qrow * LDT + li];
-            dVt[0] = mfma4(dop[0], P[qt][r], dVt[0]);
-            dVt[1] = mfma4(dop[16], P[qt][r], dVt[1]);
-            dKt[0] = mfma4(qp[0], ds[r], dKt[0]);
-            dKt[1] = mfma4(qp[16], ds[r], dKt[1]);
-            if (16 * kw + li < LDS_S && qrow < NR) dSs[qrow * LDS_S + 16 * kw + li] = ds[r];   // beyond the stride = next row
-        }
-    }
-    // lane holds dV^T / dK^T [d = 16 df + 4 kq + e][key = tk]: add LePE^T(dO) to dV and store
-    if (kvalid) {
-        const int lk = token_of(br, w, p.reso, tk);
-        const int rr = thin ? 0 : tk / br.W_sp, cc = thin ? 0 : tk - rr * br.W_sp;          // thin stripes: unused
-#pragma unroll
-        for (int df = 0; df < 2; ++df) {
-            const int d0 = 16 * df + 4 * kq;
-            // output positions that read this key through tap (ky, kx): the transposed conv
-            const f32x4 acc = thin ? lepe_taps4<true, -1>(br, Ds, Wl, rr, cc, tk, d0, dVt[df])
-                                   : lepe_taps4<false, -1>(br, Ds, Wl, rr, cc, tk, d0, dVt[df]);
-            if (d0 < p.hd) {
-                float* dst = dqkv_b + (long)lk * C3 + ch0 + d0;
-                *reinterpret_cast<f32x4*>(dst + p.C) = dKt[df] * p.scale;
-                *reinterpret_cast<f32x4*>(dst + 2 * p.C) = acc;
-            }
-        }
-    }
-    ATTN_STAMP(3);
-    __syncthreads();
-
-    // ---- phase 3: dQ^T[d][q] = scale * sum_key K[key][d] dS[q][key]; this wave owns query tile `wave` ----
-    {
-        const int qt = wave;
-        f32x4 dQt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            // columns beyond the stride read the head of the next row (finite) against K rows that are zero
-            // (rows >= NR are padded queries: any finite row will do, their dQ columns are never stored)
-            const f32x4 ds = *reinterpret_cast<const f32x4*>(&dSs[min(16 * qt + li, NR - 1) * LDS_S + 16 * kt + 4 * kq]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float* kp = &Ks[(16 * kt + 4 * kq + r) * LDT + li];
-                dQt[0] = mfma4(kp[0], ds[r], dQt[0]);
-                dQt[1] = mfma4(kp[16], ds[r], dQt[1]);
-            }
-        }
-        const int tq = 16 * qt + li;
-        if (tq < N) {
-            float* dst = dqkv_b + (long)token_of(br, w, p.reso, tq) * C3 + ch0 + 4 * kq;
-            if (4 * kq < p.hd) *reinterpret_cast<f32x4*>(dst) = dQt[0] * p.scale;
-            if (16 + 4 * kq < p.hd) *reinterpret_cast<f32x4*>(dst + 16) = dQt[1] * p.scale;
-        }
-    }
-    ATTN_STAMP(4);
-
-    // ---- LePE weight / bias gradient partials of this (window, head): dw[tap][d], db[d] ----
-    // Qs is dead after loop 2 (barrier above): reuse it as [NT waves][10][32] scratch.  Half-wave h of wave w takes
-    // tokens 2w + h, 2w + h + 2 NT, ...; the two halves meet through one cross-half shuffle.
-    float* scratch = Qs;
-    {
-        const int d = lane & 31;
-        float a[10];
-#pragma unroll
-        for (int i = 0; i < 10; ++i) a[i] = 0.f;
-        for (int t = 2 * wave + (lane >> 5); t < N; t += 2 * NT) {
-            const float g = Ds[t * LDT + d];
-            if (thin) {
-                lepe_wgrad_taps<true>(br, Vs, 0, 0, t, d, g, a);
-            } else {
-                const int rr = t / br.W_sp, cc = t - rr * br.W_sp;
-                lepe_wgrad_taps<false>(br, Vs, rr, cc, t, d, g, a);
-            }
-            a[9] += g;
-        }
-        if (thin) {                                             // a[0..2] -> taps (1, j) or (j, 1); the other six are zero
-            const bool row = br.H_sp == 1;
-            const float t0 = a[0], t1 = a[1], t2 = a[2];
-            a[0] = a[2] = a[6] = a[8] = 0.f;
-            a[1] = row ? 0.f : t0;
-            a[3] = row ? t0 : 0.f;
-            a[4] = t1;
-            a[5] = row ? t2 : 0.f;
-            a[7] = row ? 0.f : t2;
-        }
-#pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            a[i] += __shfl_xor(a[i], 32, 64);
-            if (lane < 32) scratch[(wave * 10 + i) * HD + d] = a[i];
-        }
-    }
-    ATTN_STAMP(5);
-    __syncthreads();
-    for (int i = tid; i < 10 * HD; i += NTHREADS) {
-        float sum = 0.f;
-#pragma unroll
-        for (int k = 0; k < NT; ++k) sum += scratch[k * 10 * HD + i];
-        store_lepe_partial(p, br, w, 0, i, sum);
-    }
-    ATTN_STAMP(6);
-}
-
 // sum over the 8 lanes that share lane >> 3 (quad swap, pair-of-quads swap, half-row mirror): pure VALU
 __device__ __forceinline__ float oct_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
@@ -1249,19 +1027,6 @@ inline int ds_stride_for(int N) {            // smallest stride >= N with stride
 }
 
 template <int NT>
-int launch_bwd(const AttnParams& p, int nwg, hipStream_t st) {
-    const size_t lds = (size_t)(4 * 16 * NT * LDT + w_N_rows(p) * p.ds_stride + 2 * 16 * NT + 9 * HD) * sizeof(float);
-    static size_t reserved = 0;
-    if (lds > 64 * 1024 && lds > reserved) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { cswin_set_error("attn_bwd: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return CSWIN_ERR_HIP; }
-        reserved = lds;
-    }
-    hipLaunchKernelGGL((attn_bwd_kernel<NT>), dim3(nwg), dim3(64 * NT), lds, st, p);
-    return CSWIN_OK;
-}
-
-template <int NT>
 int launch_bwd2(const AttnParams& p, int nwg, hipStream_t st) {
     const int NP = 16 * NT, S = p.ds_stride;
     const int vs_min = NP * LDT + NT * 10 * HD;
@@ -1282,7 +1047,7 @@ long long* g_attn_stamps = nullptr;     // debug only (cswin_debug_set_attn_stam
 
 extern "C" {
 
-// debug aid (not part of include/cswin_hip.h): device buffer [workgroups][8] of int64 stamped by attn_bwd_kernel wave 0
+// debug aid (not part of include/cswin_hip.h): device buffer [workgroups][8] of int64 stamped by wave 0 of the attention kernels
 void cswin_debug_set_attn_stamps(void* p) { g_attn_stamps = (long long*)p; }
 
 // qkv (B, L, 3C) -> y (B, L, C), lse (B, heads_total, L).  nbranch = 2: branch i uses channels
@@ -1359,23 +1124,10 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
         hipLaunchKernelGGL(lepe_wgrad_kernel, dim3(nwg), dim3(256), 0, st, p);
         rc = CSWIN_OK;
     } else {
-        // Two fused kernels.  attn_bwd_kernel (Q, K, V, dO and an N x N dS image in LDS, one workgroup per CU at N = 98)
-        // is the faster one for windows of up to 64 tokens; attn_bwd2_kernel (79 KB at N = 98: two workgroups per CU,
-        // delta from the saved output so that S / dP / dV / dK are one loop) wins from 65 tokens up (measured, B = 24).
-        static const char* force = getenv("CSWIN_ATTN_BWD_KERNEL");                      // tuning aid: "1" or "2"
-        const bool v1 = force ? force[0] == '1' : nt <= 4;
-        if (v1) {
-            switch (nt) {
-                case 1: case 2: case 3: case 4: rc = launch_bwd<4>(p, nwg, st); break;
-                case 5: case 6: rc = launch_bwd<6>(p, nwg, st); break;
-                default: rc = launch_bwd<7>(p, nwg, st); break;
-            }
-        } else {
-            switch (nt) {
-                case 1: case 2: case 3: case 4: rc = launch_bwd2<4>(p, nwg, st); break;
-                case 5: case 6: rc = launch_bwd2<6>(p, nwg, st); break;
-                default: rc = launch_bwd2<7>(p, nwg, st); break;
-            }
+        switch (nt) {
+            case 1: case 2: case 3: case 4: rc = launch_bwd2<4>(p, nwg, st); break;
+            case 5: case 6: rc = launch_bwd2<6>(p, nwg, st); break;
+            default: rc = launch_bwd2<7>(p, nwg, st); break;
         }
     }
     if (rc) return rc;

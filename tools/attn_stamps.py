@@ -27,9 +27,7 @@ def fwd(): call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(lse), batc
 h.cswin_debug_set_attn_stamps(ctypes.c_void_p(st.data_ptr())); (fwd if FWD else bwd)(); torch.cuda.synchronize(); h.cswin_debug_set_attn_stamps(None)
 s = st.cpu().numpy(); s = s[s[:, 0] != 0]
 print(f"stage {si+1}: {len(s)} workgroups")
-names = (["P0 load -> LDS", "P1 delta + LePE wgrad", "P2 fused loop + dK/dV", "barrier + K image", "P3 dQ", "slab reduce + store"]
-         if os.environ.get("CSWIN_ATTN_BWD_KERNEL", "2" if si == 2 else "1") == "2" else
-         ["load -> LDS", "loop1 (S, dP, delta)", "loop2 (dV, dK, dS)", "barrier + dQ", "LePE wgrad", "slab reduce + store"])
+names = ["P0 load -> LDS", "P1 delta + LePE wgrad", "P2 fused loop + dK/dV", "barrier + K image", "P3 dQ", "slab store"]
 if FWD: names = ["K/V -> LDS", "S + softmax (tile 0)", "PV (tile 0)", "LePE + store (+ more tiles)"]
 for k, nm in enumerate(names):
     d = s[:, k + 1] - s[:, k]
