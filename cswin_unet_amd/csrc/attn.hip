@@ -371,12 +371,6 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
     const int tk = 16 * kw + li;                       // this lane's key token
     const bool kvalid = tk < N;
     const int lk = kvalid ? token_of(br, w, p.reso, tk) : 0;
-    f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0;
-    if (kvalid && 8 * kq < p.hd) {
-        const float* src = qkv_b + (long)lk * C3 + p.C + ch0 + 8 * kq;
-        k0 = *reinterpret_cast<const f32x4*>(src);
-        k1 = *reinterpret_cast<const f32x4*>(src + 4);
-    }
     f32x4 qv[2], vv[2], dv[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -419,19 +413,7 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
     __syncthreads();
     ATTN_STAMP(1);
 
-    // ---- P1: V fragment; per token: LePE weight-gradient terms, and delta = sum_d dO (y - bias - sum_tap W V_nbr) ----
-    float kf[8], vf[8];
-    {
-        const float* vp = &VS[tk * LDT + 8 * kq];
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp), v1 = *reinterpret_cast<const f32x4*>(vp + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            kf[e] = k0[e];
-            kf[4 + e] = k1[e];
-            vf[e] = v0[e];
-            vf[4 + e] = v1[e];
-        }
-    }
+    // ---- P1: per token: LePE weight-gradient terms, and delta = sum_d dO (y - bias - sum_tap W V_nbr) ----
     // Eight lanes per token, four channels per lane: neighbour index and validity are computed once per 16 B instead of
     // once per float, the taps are b128 LDS reads, delta is an 8-lane DPP sum.  The wave's [10][32] gradient partial goes
     // to the part of the VS region that the V image does not use; it is combined over the waves after the barrier.
@@ -506,6 +488,26 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
         if (lane < 8) {
 #pragma unroll
             for (int i = 0; i < 10; ++i) *reinterpret_cast<f32x4*>(&slab[(wave * 10 + i) * HD + 4 * lane]) = a4[i];
+        }
+    }
+    // K / V fragments of this wave's 16 keys (B operands of P2): fetched only now, so that they do not sit in registers
+    // through P1 (whose accumulators would otherwise spill); the K load's latency hides behind the two barriers below
+    float kf[8], vf[8];
+    {
+        f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0;
+        if (kvalid && 8 * kq < p.hd) {
+            const float* src = qkv_b + (long)lk * C3 + p.C + ch0 + 8 * kq;
+            k0 = *reinterpret_cast<const f32x4*>(src);
+            k1 = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+        const float* vp = &VS[tk * LDT + 8 * kq];
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp), v1 = *reinterpret_cast<const f32x4*>(vp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            kf[e] = k0[e];
+            kf[4 + e] = k1[e];
+            vf[e] = v0[e];
+            vf[4 + e] = v1[e];
         }
     }
     ATTN_STAMP(2);
@@ -591,8 +593,8 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
     // ---- P3: K image over Q, then dQ ----
     {
         float* kp = &QK[tk * LDT + 8 * kq];
-        *reinterpret_cast<f32x4*>(kp) = k0;
-        *reinterpret_cast<f32x4*>(kp + 4) = k1;
+        *reinterpret_cast<f32x4*>(kp) = f32x4{kf[0], kf[1], kf[2], kf[3]};
+        *reinterpret_cast<f32x4*>(kp + 4) = f32x4{kf[4], kf[5], kf[6], kf[7]};
     }
     __syncthreads();
     ATTN_STAMP(4);
