@@ -1,14 +1,14 @@
 """Synapse slice / volume reader and training augmentation.
 
-Host-side mirror of the reference's datasets/dataset_synapse.py:12-83 with the same names, sample schema and RNG
-consumption order (``random.random`` for the branch choice, ``np.random.randint`` for k / axis / angle), so a seeded
-run produces the same augmented batch as the reference (tests/test_host_next_rows.py checks this against
-tests/golden/g9_augment.npz, generated from the reference itself).  The arithmetic (rot90, flip, order-0 rotate,
-cubic / nearest zoom) is numpy / scipy, exactly the libraries the reference calls; nothing here runs on the GPU.
+Host-side counterpart of the reference's datasets/dataset_synapse.py:12-83: same public names, sample schema and -- this is
+what makes a seeded run reproduce the reference's batches -- the same consumption order of the two RNG streams
+(`random.random()` picks the branch, `np.random.randint` draws k / axis / angle).  tests/test_host_next_rows.py checks the
+outputs against tests/golden/g9_augment.npz, which was produced by the reference itself.  The arithmetic (rot90, flip,
+order-0 rotate, cubic / nearest zoom) is numpy / scipy, exactly the libraries the reference calls; nothing here touches the GPU.
 
-Training slices: ``<base_dir>/<name>.npz`` with ``image`` (H, W) float32 in [0, 1] and ``label`` (or ``segmentation``)
-(H, W) class ids (:62-69).  Test volumes: ``<base_dir>/<name>.npy.h5`` with ``image``/``label`` (or
-``images``/``segmentations``) (:70-77); h5py is optional in this image, so ``<name>.npz`` volumes are accepted too.
+Training slices: `<base_dir>/<name>.npz` holding `image` (H, W) float32 in [0, 1] and `label` (or `segmentation`) (H, W)
+class ids (:62-69).  Test volumes: `<base_dir>/<name>.npy.h5` with `image`/`label` or `images`/`segmentations` (:70-77);
+h5py is optional in this image, so `<name>.npz` volumes are accepted as well.
 """
 import os
 import random
@@ -16,85 +16,97 @@ import random
 import numpy as np
 import torch
 from scipy import ndimage
-from scipy.ndimage import zoom
 from torch.utils.data import Dataset
+
+_NEAREST, _CUBIC = 0, 3
 
 
 def random_rot_flip(image, label):
-    """rot90 by k in {0..3}, then flip along a random axis (dataset_synapse.py:12-19)."""
-    k = np.random.randint(0, 4)
-    image, label = np.rot90(image, k), np.rot90(label, k)
-    axis = np.random.randint(0, 2)
-    return np.flip(image, axis=axis).copy(), np.flip(label, axis=axis).copy()
+    """Quarter turns (k drawn from {0..3}) followed by a flip along a drawn axis; the same transform for both arrays (:12-19)."""
+    quarter_turns = np.random.randint(0, 4)
+    flip_axis = None
+    out = []
+    for arr in (image, label):
+        arr = np.rot90(arr, quarter_turns)
+        if flip_axis is None:
+            flip_axis = np.random.randint(0, 2)         # drawn after the rotations, like the reference
+        out.append(arr)
+    return tuple(np.flip(arr, axis=flip_axis).copy() for arr in out)
 
 
 def random_rotate(image, label):
-    """rotate by an integer angle in [-20, 20), nearest neighbour for both, same shape (:22-26)."""
-    angle = np.random.randint(-20, 20)
-    return (ndimage.rotate(image, angle, order=0, reshape=False), ndimage.rotate(label, angle, order=0, reshape=False))
+    """Rotation by an integer angle from [-20, 20), nearest neighbour for image and label alike, shape kept (:22-26)."""
+    degrees = np.random.randint(-20, 20)
+    turn = lambda arr: ndimage.rotate(arr, degrees, order=_NEAREST, reshape=False)
+    return turn(image), turn(label)
+
+
+def _resize_pair(image, label, size):
+    """Cubic zoom of the image and nearest zoom of the label to `size` when the shape differs (:41-43)."""
+    h, w = image.shape
+    if (h, w) == tuple(size):
+        return image, label
+    factors = (size[0] / h, size[1] / w)
+    return ndimage.zoom(image, factors, order=_CUBIC), ndimage.zoom(label, factors, order=_NEAREST)
 
 
 class RandomGenerator(object):
-    """sample {'image': (H, W), 'label': (H, W)} -> {'image': float32 (1, h, w), 'label': int64 (h, w)} (:29-47)."""
+    """{'image': (H, W), 'label': (H, W)} -> {'image': float32 (1, h, w), 'label': int64 (h, w)} (:29-47)."""
 
     def __init__(self, output_size):
         self.output_size = output_size
 
     def __call__(self, sample):
-        image, label = sample['image'], sample['label']
+        pair = (sample['image'], sample['label'])
+        # one uniform draw decides "rot90 + flip"; only if that fails a second draw decides "small rotation"
         if random.random() > 0.5:
-            image, label = random_rot_flip(image, label)
+            pair = random_rot_flip(*pair)
         elif random.random() > 0.5:
-            image, label = random_rotate(image, label)
-        x, y = image.shape
-        if x != self.output_size[0] or y != self.output_size[1]:
-            image = zoom(image, (self.output_size[0] / x, self.output_size[1] / y), order=3)
-            label = zoom(label, (self.output_size[0] / x, self.output_size[1] / y), order=0)
-        image = torch.from_numpy(image.astype(np.float32)).unsqueeze(0)
-        label = torch.from_numpy(label.astype(np.float32))
-        return {'image': image, 'label': label.long()}
+            pair = random_rotate(*pair)
+        image, label = _resize_pair(*pair, self.output_size)
+        image_t = torch.from_numpy(image.astype(np.float32)).unsqueeze(0)
+        label_t = torch.from_numpy(label.astype(np.float32)).long()
+        return {'image': image_t, 'label': label_t}
+
+
+def _first_key(data, *names):
+    for n in names:
+        if n in data:
+            return data[n][:]
+    raise KeyError(f"none of {names} in {list(data.keys())}")
 
 
 class Synapse_dataset(Dataset):
-    """split == 'train': 2-D slices from .npz; otherwise whole volumes (:50-83).  ``list_dir/<split>.txt`` names the cases."""
+    """split == 'train': 2-D slices from .npz; any other split: whole volumes (:50-83).  `list_dir/<split>.txt` names the cases."""
 
     def __init__(self, base_dir, list_dir, split, transform=None, is_kits=False, is_lits=False):
-        self.transform = transform
-        self.split = split
-        with open(os.path.join(list_dir, self.split + '.txt')) as f:
+        self.data_dir, self.split, self.transform, self.is_kits = base_dir, split, transform, is_kits
+        with open(os.path.join(list_dir, split + '.txt')) as f:
             self.sample_list = f.readlines()
-        self.data_dir = base_dir
-        self.is_kits = is_kits
 
     def __len__(self):
         return len(self.sample_list)
 
-    @staticmethod
-    def _pick(data, *names):
-        for n in names:
-            if n in data:
-                return data[n][:]
-        raise KeyError(f"none of {names} in {list(data.keys())}")
+    def _read_slice(self, name):
+        data = np.load(os.path.join(self.data_dir, name + '.npz'))
+        return data['image'], _first_key(data, 'label', 'segmentation')
+
+    def _read_volume(self, name):
+        h5 = self.data_dir + "/{}.npy.h5".format(name)
+        if not os.path.exists(h5):
+            data = np.load(os.path.join(self.data_dir, name + '.npz'))
+            return _first_key(data, 'image', 'images'), _first_key(data, 'label', 'segmentations')
+        try:
+            import h5py
+        except ImportError as e:
+            raise RuntimeError(f"{h5}: reading test volumes in HDF5 needs h5py, which is not installed; "
+                               f"convert the volume to {name}.npz (image, label)") from e
+        with h5py.File(h5, "r") as data:
+            return _first_key(data, 'image', 'images'), _first_key(data, 'label', 'segmentations')
 
     def __getitem__(self, idx):
         name = self.sample_list[idx].strip('\n')
-        if self.split == "train":
-            data = np.load(os.path.join(self.data_dir, name + '.npz'))
-            image, label = data['image'], self._pick(data, 'label', 'segmentation')
-        else:
-            h5 = self.data_dir + "/{}.npy.h5".format(name)
-            if os.path.exists(h5):
-                try:
-                    import h5py
-                except ImportError as e:
-                    raise RuntimeError(f"{h5}: reading test volumes in HDF5 needs h5py, which is not installed; "
-                                       f"convert the volume to {name}.npz (image, label)") from e
-                with h5py.File(h5, "r") as data:
-                    image = self._pick(data, 'image', 'images')
-                    label = self._pick(data, 'label', 'segmentations')
-            else:
-                data = np.load(os.path.join(self.data_dir, name + '.npz'))
-                image, label = self._pick(data, 'image', 'images'), self._pick(data, 'label', 'segmentations')
+        image, label = (self._read_slice if self.split == "train" else self._read_volume)(name)
         sample = {'image': image, 'label': label}
         if self.transform:
             sample = self.transform(sample)
