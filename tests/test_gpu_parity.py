@@ -123,6 +123,42 @@ def test_linear_fwd_bwd(ops, M, Nn, K):
     rel_err(bd.grad, br.grad, tag + ".db")
 
 
+@pytest.mark.parametrize("shapes", [[(4704, 256, 1024), (4704, 1024, 256), (4704, 256, 256), (4704, 768, 256)],
+                                    [(3000, 64, 64)], [(777, 130, 100), (777, 64, 100)], [(1176, 512, 2048), (1176, 2048, 512)]])
+def test_linear_weight_gradient_batch(shapes):
+    """cswin_linear_bwd_weight_batch through the C ABI: 1-4 problems in one launch (with and without DropPath row scales and
+    bias), including a problem whose N is not a multiple of 4 (falls back to separate launches), vs torch."""
+    import ctypes
+    from cswin_unet_amd._lib import ReduceJob, WgradDesc, call, lib, stream
+    n = len(shapes)
+    wg, jobs, keep, refs = (WgradDesc * n)(), (ReduceJob * n)(), [], []
+    for i, (M, N_, K) in enumerate(shapes):
+        dy, x = det_normal(f"wb.dy{i}", (M, N_)), det_normal(f"wb.x{i}", (M, K))
+        rps = M // 3
+        rs = np.array([0.0, 1.25, 0.5], np.float32) if i % 2 == 0 else None
+        with_bias = i != 1
+        dyd, xd = T(dy), T(x)
+        rsd = T(rs) if rs is not None else None
+        dw = torch.empty(N_, K, device=DEV)
+        db = torch.empty(N_, device=DEV) if with_bias else None
+        nbytes = lib().cswin_linear_bwd_weight_workspace(M, N_, K)
+        ws = torch.empty(nbytes // 4 + 4, device=DEV)
+        keep += [dyd, xd, rsd, ws]
+        wg[i].dy, wg[i].x, wg[i].row_scale = dyd.data_ptr(), xd.data_ptr(), (rsd.data_ptr() if rsd is not None else None)
+        wg[i].dw, wg[i].dbias, wg[i].workspace, wg[i].ws_bytes = dw.data_ptr(), (db.data_ptr() if with_bias else None), ws.data_ptr(), nbytes
+        wg[i].rows_per_sample, wg[i].M, wg[i].N, wg[i].K = rps, M, N_, K
+        scale = np.ones((M, 1), np.float32) if rs is None else np.repeat(rs, rps)[:M, None] if M % 3 == 0 else None
+        if scale is None:                                  # M not divisible by 3: build the per-row scale explicitly
+            scale = np.array([rs[min(m // rps, 2)] for m in range(M)], np.float32)[:, None]
+        refs.append((dw, db, (torch.from_numpy(dy * scale).T @ torch.from_numpy(x)), torch.from_numpy(dy * scale).sum(0)))
+    call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), n, ctypes.cast(jobs, ctypes.c_void_p), stream())
+    call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), n, stream())
+    for i, (dw, db, dw_ref, db_ref) in enumerate(refs):
+        rel_err(dw, dw_ref, f"wgrad_batch.{i}.dw")
+        if db is not None:
+            rel_err(db, db_ref, f"wgrad_batch.{i}.db")
+
+
 def test_linear_concat_residual_droppath(ops):
     B, L, C = 3, 196, 256
     skip, x = det_normal("cl.skip", (B, L, C)), det_normal("cl.x", (B, L, C))
