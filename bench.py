@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: CSWin-UNet (cswin_tiny_224_lite) training images/sec on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: spawns its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = forward -> 0.4*CE + 0.6*Dice -> backward (-> RCCL all-reduce) -> SGD(momentum) update on a synthetic
@@ -174,11 +174,49 @@ def cpu_baseline(batch, steps=2):
                       f"torch-CPU oracle (oracle/cswin_oracle.py)", "ms_per_step": round(dt * 1e3, 1)}
 
 
+def _spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes (one rank per GPU, RCCL over xGMI) with
+    the torchrun environment and relay rank 0's JSON line.  Decided BEFORE anything in this process touches the GPU: the
+    parent never initialises HIP and never re-execs -- it only waits for its children and returns the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this host driver (RCCL needs it)
+        # rank 0 inherits stdout (the one JSON line); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:                    # a dead rank leaves the others blocked in a collective
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=24, help="images per GPU")
     ap.add_argument("--cfg", default=os.path.join(ROOT, "configs", "cswin_tiny_224_lite.yaml"))
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying hipGraphs")
@@ -191,13 +229,21 @@ def main():
     ap.add_argument("--img-size", type=int, default=None, help="override DATA.IMG_SIZE (384 uses split [1,2,12,12])")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_spawn_ranks(args.gpus, sys.argv[1:]))
+
     from cswin_unet_amd.config import get_config
     from cswin_unet_amd.networks.vision_transformer import CSwinUnet
     from cswin_unet_amd.trainer import DataParallelTrainer, init_distributed, synthetic_batch
 
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world_env}")
+    n_dev = torch.cuda.device_count()                # counting devices does not initialise HIP
+    if n_dev < args.gpus and not (n_dev >= 1 and os.environ.get("CSWIN_DIST_BACKEND") == "gloo"):   # gloo: ranks may share a GPU (rehearsal)
+        sys.exit(f"bench.py rank {os.environ.get('RANK', '0')}: needs {args.gpus} HIP device(s), this host shows {n_dev} "
+                 f"(there is no CPU path)")
     rank, local, world, group = init_distributed()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path)"
     dev = torch.device("cuda", torch.cuda.current_device())
     over = {}
     if args.img_size:

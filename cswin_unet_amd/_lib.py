@@ -54,6 +54,8 @@ SIGNATURES = {
     "cswin_loss_bwd": (I, [P, P, P, P, P, F, F, I, I, L, P]),
     "cswin_sgd_flat": (I, [P, P, P, L, P, F, F, F, P]),
     "cswin_multi_copy": (I, [P, I, P]),
+    "cswin_pack_bf16": (I, [P, P, L, P]),
+    "cswin_unpack_bf16": (I, [P, P, L, P]),
 }
 
 

@@ -875,8 +875,10 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
         // 1024 workgroups per launch, i.e. exactly 4 per CU, shared by the problems (measured with four problems: 192 / 256 /
         // 320 per problem -> 13.80 / 13.55 / 14.09 ms per step); a quarter of the slab traffic of four stand-alone launches
         static const int batch_env = getenv("CSWIN_GEMM_BATCH_WGS") ? atoi(getenv("CSWIN_GEMM_BATCH_WGS")) : 0;   // tuning aid
-        const int batch_target = batch_env > 0 ? batch_env : 1024 / n;
+        const int batch_target = batch_env > 0 ? (batch_env < 1024 ? batch_env : 1024) : 1024 / n;   // the workspace query covers <= 1024
         choose_split(M, N, K, &splits, &rps, batch_target);
+        CSWIN_REQUIRE((size_t)splits * ((size_t)N * K + N) * sizeof(float) <= d[i].ws_bytes, CSWIN_ERR_WORKSPACE,
+                      "linear_bwd_weight_batch: %d slabs do not fit problem %d's workspace", splits, i);
         float* slab = (float*)d[i].workspace;
         const long slab_stride = (long)N * K + N;
         Epilogue e = plain_epilogue(slab, K);

@@ -36,6 +36,9 @@ __global__ __launch_bounds__(256) void loss_sums_kernel(const float* __restrict_
         }
         const float inv = 1.0f / sum;
         const int lab = (int)labels[i];
+        // nn.CrossEntropyLoss raises on a target outside [0, ncls) (trainer.py:40,55); without a host sync the device-side
+        // equivalent is to poison the CE sum: the step's loss reads NaN instead of a silently biased value
+        if ((unsigned)lab >= (unsigned)NC) acc[0] = __builtin_nanf("");
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const float pc = v[c] * inv;

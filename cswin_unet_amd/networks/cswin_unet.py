@@ -104,17 +104,19 @@ class CSWinBlock(nn.Module):
                        drop=drop)
         self.norm2 = norm_layer(dim)
 
-    def _keep_scale(self, x):
-        """Per-sample DropPath factor (mask / keep_prob) or None; one draw per residual branch like the reference.
-        CSWinTransformer pre-draws the factors of ALL blocks in one launch (self._dp_preset) to avoid 2 tiny RNG
-        launches per block; a block used on its own draws them itself."""
+    def _keep_scales(self, x):
+        """Per-sample DropPath factors (mask / keep_prob) of the two residual branches, or (None, None); one draw per
+        branch like the reference.  CSWinTransformer pre-draws the factors of ALL blocks in one launch (self._dp_preset)
+        to avoid 2 tiny RNG launches per block; the preset is READ, never consumed, so an activation-checkpoint recompute
+        of this block (use_chk) sees the factors its forward used.  A block used on its own draws them itself (there
+        torch.utils.checkpoint's preserved RNG state makes the recompute repeat the draw)."""
         dp = self.drop_path
         if isinstance(dp, DropPath) and self.training and dp.drop_prob > 0.:
             preset = getattr(self, "_dp_preset", None)
             if preset:
-                return preset.pop(0)
-            return dp.sample_scale(x.shape[0], x.device)
-        return None
+                return preset[0], preset[1]
+            return dp.sample_scale(x.shape[0], x.device), dp.sample_scale(x.shape[0], x.device)
+        return None, None
 
     def forward(self, x):
         B, L, C = x.shape
@@ -127,7 +129,7 @@ class CSWinBlock(nn.Module):
             raise NotImplementedError("Mlp dropout p > 0 is not implemented on the HIP path (reference uses 0)")
         if type(self.norm1) is not nn.LayerNorm or type(self.norm2) is not nn.LayerNorm:
             raise NotImplementedError("the HIP block fuses nn.LayerNorm only")
-        rs1, rs2 = self._keep_scale(x), self._keep_scale(x)
+        rs1, rs2 = self._keep_scales(x)
         return ops.cswin_block(x, self.patches_resolution, self.split_size, [m.idx for m in a], [m.num_heads for m in a],
                                a[0].scale, self.norm1, self.qkv, self.proj, self.norm2, self.mlp.fc1, self.mlp.fc2,
                                [m.get_v.weight for m in a], [m.get_v.bias for m in a], rs1, rs2)

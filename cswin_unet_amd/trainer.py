@@ -40,7 +40,9 @@ def init_distributed():
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # "nccl" IS RCCL on ROCm.  CSWIN_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsals on a 1-GPU box:
+        # RCCL refuses two ranks on one device); the protocol is the same, only the transport differs.
+        backend = os.environ.get("CSWIN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world, (dist.group.WORLD if world > 1 else None)
 
@@ -89,6 +91,7 @@ class HipEngine:
         self.stats = torch.zeros(3, dtype=torch.float32, device=dev)          # [loss, ce, dice] of the last step
         self._coef = torch.zeros(2 * num_classes, dtype=torch.float32, device=dev)
         self.use_graph, self._graphs, self._logits = use_graph, None, None
+        self._wire = {}
         from . import ops
         ops.set_wgrad_overlap(os.environ.get("CSWIN_WGRAD_OVERLAP", "0") != "0")
 
@@ -255,6 +258,20 @@ class HipEngine:
     def apply(self, grad_scale):
         self.opt.apply(grad_scale)
 
+    # bf16 gradient wire (HIP kernels; the wire buffer of a bucket is allocated once and reused every step)
+    def pack_wire(self, chunk, dtype):
+        if dtype != torch.bfloat16:
+            raise ValueError(f"HipEngine wire dtype {dtype}: only torch.bfloat16 is implemented")
+        key = (chunk.data_ptr(), chunk.numel())
+        wire = self._wire.get(key)
+        if wire is None:
+            wire = self._wire[key] = torch.empty(chunk.numel(), dtype=torch.bfloat16, device=chunk.device)
+        call("cswin_pack_bf16", ptr(chunk), ptr(wire), chunk.numel(), stream())
+        return wire
+
+    def unpack_wire(self, wire, chunk):
+        call("cswin_unpack_bf16", ptr(wire), ptr(chunk), chunk.numel(), stream())
+
 
 class DataParallelTrainer:
     """The data-parallel protocol of one step (device agnostic; see module docstring)."""
@@ -306,12 +323,17 @@ class DataParallelTrainer:
                     if self.allreduce_dtype is None:
                         works.append((dist.all_reduce(chunk, group=self.group, async_op=True), None, None))
                     else:
-                        wire = chunk.to(self.allreduce_dtype)
+                        pack = getattr(eng, "pack_wire", None)          # HipEngine: HIP pack kernel into a persistent wire buffer
+                        wire = pack(chunk, self.allreduce_dtype) if pack else chunk.to(self.allreduce_dtype)
                         works.append((dist.all_reduce(wire, group=self.group, async_op=True), chunk, wire))
         for w, chunk, wire in works:
             w.wait()
             if wire is not None:
-                chunk.copy_(wire)
+                unpack = getattr(eng, "unpack_wire", None)
+                if unpack:
+                    unpack(wire, chunk)
+                else:
+                    chunk.copy_(wire)
         eng.apply(grad_scale=1.0 / world)
         self.iter_num += 1
         eng.set_lr(poly_lr(self.base_lr, self.iter_num - 1, self.max_iterations))   # trainer.py:61-63
@@ -366,7 +388,6 @@ def trainer_synapse(args, model, snapshot_path, group=None, log_every=1):
     import random
     import sys
 
-    import numpy as np
     from torch.utils.data import DataLoader
     from torch.utils.data.distributed import DistributedSampler
 
@@ -387,16 +408,22 @@ def trainer_synapse(args, model, snapshot_path, group=None, log_every=1):
     print("The length of train set is: {}".format(len(db_train)))
     seed = getattr(args, "seed", 1234)
 
-    def worker_init_fn(worker_id):                                   # trainer.py:33-34
-        random.seed(seed + worker_id)
-        np.random.seed(seed + worker_id)
+    n_workers = getattr(args, "num_workers", 8)
+
+    def worker_init_fn(worker_id):
+        # trainer.py:33-34 seeds `random` only, with seed + worker_id.  Under data parallelism every rank would then share
+        # one augmentation coin-flip stream, so the seed is offset by rank * num_workers (rank 0 = the reference's seeds).
+        random.seed(seed + rank * max(n_workers, 1) + worker_id)
 
     sampler = DistributedSampler(db_train, num_replicas=world, rank=rank, shuffle=True, seed=seed) if world > 1 else None
     loader = DataLoader(db_train, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler,
-                        num_workers=getattr(args, "num_workers", 8), pin_memory=True, drop_last=True,
-                        worker_init_fn=worker_init_fn, persistent_workers=getattr(args, "num_workers", 8) > 0)
+                        num_workers=n_workers, pin_memory=True, drop_last=True, worker_init_fn=worker_init_fn,
+                        persistent_workers=False)    # like the reference: workers are re-created and re-seeded every epoch
     max_epoch = args.max_epochs
     max_iterations = max_epoch * len(loader)
+    if max_iterations == 0:
+        raise ValueError(f"trainer_synapse: {len(db_train)} samples give no full batch of {args.batch_size} per rank "
+                         f"(the captured step has a fixed batch shape, the last incomplete batch is dropped)")
     logging.info("{} iterations per epoch. {} max iterations ".format(len(loader), max_iterations))
     model.train()
     trainer = DataParallelTrainer(model, args.num_classes, base_lr=args.base_lr, max_iterations=max_iterations, group=group)

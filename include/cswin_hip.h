@@ -177,6 +177,10 @@ int cswin_sgd_flat(float* p, const float* g, float* m, long n, const float* lr_d
                    float weight_decay, float grad_scale, void* stream);
 /* table: device array of {const float* src; float* dst; long long n;} (24-byte records), one workgroup each */
 int cswin_multi_copy(const void* table, int nchunks, void* stream);
+/* bf16 gradient wire for the data-parallel all-reduce (replaces DataParallel's fp32 reduce_add, trainer.py:37-38):
+   fp32 -> bf16 round-to-nearest-even / bf16 -> fp32 over n elements (src of pack, dst of unpack 16-B aligned) */
+int cswin_pack_bf16(const float* src, void* dst_bf16, long n, void* stream);
+int cswin_unpack_bf16(const void* src_bf16, float* dst, long n, void* stream);
 
 #ifdef __cplusplus
 }

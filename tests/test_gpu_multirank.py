@@ -1,0 +1,116 @@
+"""The product engine (HipEngine: C-ABI kernels, hipGraphs, phased backward) under data parallelism with TWO real rank
+processes: 2 ranks x 1 image reproduce the reference's DataParallel semantics (loss on the gathered global batch,
+trainer.py:28,37-38,54-57) -- the g5 golden 3-step SGD loss trajectory and weight checksum of the B=2 batch.
+
+Transport: RCCL ("nccl") when the box has >= 2 GPUs; on a 1-GPU box both ranks share cuda:0 over gloo (RCCL refuses two
+ranks on one device).  The protocol under test -- graph A -> 28-float loss all-reduce -> finalize -> graph B1/B2/B3 with the
+bucketed gradient all-reduces between them, async handles, 1/world scaling, bf16 wire pack/unpack -- is the same code
+either way; only dist's backend differs.  Also runs bench.py --gpus 2 through its own spawner."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, backend, wire, use_graph, out):
+    import torch.distributed as dist
+    from cswin_unet_amd.networks import cswin_unet as N
+    from cswin_unet_amd.trainer import DataParallelTrainer
+    from oracle.determ import det_labels, det_normal, fill_state_dict
+    n_dev = torch.cuda.device_count()
+    torch.cuda.set_device(rank % n_dev)
+    dev = torch.device("cuda", rank % n_dev)
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    net = N.CSWinTransformer(img_size=224, num_classes=9, embed_dim=64, depth=[1, 2, 9, 1], split_size=[1, 2, 7, 7],
+                             num_heads=[2, 4, 8, 16], mlp_ratio=4., qkv_bias=True, drop_path_rate=0.).to(dev)
+    fill_state_dict(net).train()
+    if rank != 0:                       # replicas must come from rank 0's broadcast, not from identical construction
+        with torch.no_grad():
+            for p in net.parameters():
+                p.mul_(0.5)
+    img = torch.from_numpy(det_normal("model.x", (2, 1, 224, 224))).repeat(1, 3, 1, 1)[rank:rank + 1].to(dev)
+    lab = torch.from_numpy(det_labels("model.labels", (2, 224, 224), 9))[rank:rank + 1].to(dev)
+    tr = DataParallelTrainer(net, 9, base_lr=0.05, max_iterations=100, group=dist.group.WORLD, use_graph=use_graph,
+                             allreduce_dtype=torch.bfloat16 if wire == "bf16" else None)
+    assert tr.collectives and tr.world == 2
+    losses = [float(tr.train_step(img, lab)[0]) for _ in range(3)]
+    chk = sum(float(p.detach().double().abs().sum()) for p in net.parameters())
+    out.put((rank, losses, chk))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_two_ranks(wire, use_graph):
+    import torch.multiprocessing as mp
+    n_dev = torch.cuda.device_count()
+    backend = "nccl" if n_dev >= 2 else "gloo"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, backend, wire, use_graph, q), daemon=True) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(2):
+            r, losses, chk = q.get(timeout=420)
+            res[r] = (losses, chk)
+    finally:
+        for p in procs:
+            p.join(120)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return res, backend
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_two_ranks_hip_engine_reproduce_global_batch_trajectory(golden, use_graph):
+    g = golden("g5_model")
+    res, backend = _run_two_ranks("fp32", use_graph)
+    for r in (0, 1):
+        losses, chk = res[r]
+        assert np.allclose(losses, g["sgd_losses"], rtol=2e-3), (backend, r, losses, g["sgd_losses"])
+        assert abs(chk - float(g["sgd_weight_checksum"])) <= 1e-4 * float(g["sgd_weight_checksum"]), (backend, r)
+    assert res[0][0] == res[1][0] or np.allclose(res[0][0], res[1][0], rtol=1e-6)       # both ranks report the GLOBAL loss
+    assert abs(res[0][1] - res[1][1]) <= 1e-7 * res[0][1]                                # replicas stay identical
+
+
+def test_two_ranks_bf16_gradient_wire(golden):
+    """BASELINE configs[2]: bf16 gradients on the wire (HIP pack / unpack kernels around the collective).  The first loss uses
+    no gradient and must match exactly; later losses stay within the bf16 rounding of the update."""
+    g = golden("g5_model")
+    res, _ = _run_two_ranks("bf16", True)
+    losses, _ = res[0]
+    assert abs(losses[0] - g["sgd_losses"][0]) < 2e-3 * g["sgd_losses"][0]
+    assert np.allclose(losses, g["sgd_losses"], rtol=3e-2), (losses, g["sgd_losses"])
+    assert abs(res[0][1] - res[1][1]) <= 1e-7 * res[0][1]
+
+
+def test_bench_two_ranks_through_its_own_spawner():
+    """`python bench.py --gpus 2` with no launcher: rank 0 prints the one JSON line with n_gpus 2 and the global batch."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if torch.cuda.device_count() < 2:
+        env["CSWIN_DIST_BACKEND"] = "gloo"               # both ranks on the one GPU (rehearsal: not a scaling number)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "4", "--skip-roofline", "--skip-cpu"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["steps"] == 3

@@ -745,3 +745,99 @@ def test_model_bf16_operands_training_step(N, ops, golden, bf16_matmul):
     params = dict(net.named_parameters())
     for n in ["stage3.4.qkv.weight", "merge2.conv.weight", "upsample1.encoder.weight", "output.weight", "concat_linear3.weight"]:
         assert packed_err(params[n].grad, f"grad.{n}.") < 0.4, n
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE full sizes: one whole training step against the CPU oracle (every B-dependent dispatch branch: GEMM tile and
+# split-K choices, the attention query-split heuristic, the batched weight-gradient launch, CARAFE slab sizing)
+# ------------------------------------------------------------------------------------------------------------------
+FULL_GRADS = ["stage1_conv_embed.0.weight", "stage1.0.qkv.weight", "stage1.0.attns.0.get_v.weight", "merge1.conv.weight",
+              "stage2.1.mlp.fc1.weight", "stage2.0.attns.1.get_v.bias", "merge2.conv.weight", "stage3.0.proj.weight",
+              "stage3.4.qkv.weight", "stage3.8.mlp.fc2.weight", "stage3.4.attns.1.get_v.weight", "stage3.2.norm1.weight",
+              "merge3.conv.weight", "stage4.0.qkv.bias", "stage4.0.attns.0.get_v.weight", "norm.weight",
+              "stage_up4.0.mlp.fc1.weight", "upsample4.encoder.weight", "upsample4.out.weight", "concat_linear4.weight",
+              "stage_up3.5.qkv.weight", "stage_up3.0.norm2.bias", "upsample3.down.weight", "concat_linear3.weight",
+              "stage_up2.1.proj.weight", "upsample2.encoder.weight", "concat_linear2.weight", "stage_up1.0.mlp.fc2.weight",
+              "upsample1.encoder.weight", "upsample1.down.weight", "upsample1.out.weight", "norm_up.weight", "output.weight"]
+
+
+def _full_size_step(N, ops, img_size, batch, split, tag):
+    cfg = dict(O.TINY_224, img_size=img_size, split_size=tuple(split))
+    net = N.CSWinTransformer(img_size=img_size, num_classes=9, embed_dim=64, depth=[1, 2, 9, 1], split_size=list(split),
+                             num_heads=[2, 4, 8, 16], qkv_bias=True, drop_path_rate=0.).to(DEV)
+    fill_state_dict(net).train()
+    g = torch.Generator().manual_seed(20260)
+    img = torch.randn(batch, 3, img_size, img_size, generator=g)
+    lab = torch.randint(0, 9, (batch, img_size, img_size), generator=g)
+    logits = net(img.to(DEV))
+    loss, stats = ops.ce_dice_loss(logits, lab.to(DEV))
+    loss.backward()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    P = O.golden_params(cfg)
+    ref_logits = O.cswin_forward(P, img, cfg)
+    ref_loss, ref_ce, ref_dice = O.ce_dice_loss(ref_logits, lab)
+    ref_loss.backward()
+    rel_err(logits, ref_logits, f"{tag}.logits")
+    assert abs(float(loss) - float(ref_loss)) < 1e-3 * abs(float(ref_loss))
+    assert abs(float(stats[1]) - float(ref_ce)) < 1e-3 * abs(float(ref_ce))
+    assert abs(float(stats[2]) - float(ref_dice)) < 1e-3 * abs(float(ref_dice))
+    params = dict(net.named_parameters())
+    for n in FULL_GRADS:
+        rel_err(params[n].grad, P[n].grad, f"{tag}.grad.{n}")
+
+
+def test_full_size_training_step_b24_vs_oracle(N, ops):
+    """BASELINE configs[1] exactly as bench.py times it (cswin_tiny_224_lite, B = 24, fp32): logits, loss, CE, Dice and 33
+    parameter gradients covering every stage, both CARAFE kinds, the merges, the skips and the head at RTOL 1e-3."""
+    _full_size_step(N, ops, 224, 24, (1, 2, 7, 7), "full224b24")
+
+
+def test_full_size_training_step_384_b8_vs_oracle(N, ops):
+    """BASELINE configs[3] shape at the batch bench.py uses for it (384 x 384, split [1,2,12,12], B = 8)."""
+    _full_size_step(N, ops, 384, 8, (1, 2, 12, 12), "full384b8")
+
+
+def test_use_chk_with_drop_path_matches_plain_backward(N, ops):
+    """Activation checkpointing (use_chk, cswin_unet.py:329-331,468-532) with stochastic depth: the recompute in backward
+    must reuse the DropPath factors the forward drew (they used to be popped and re-drawn)."""
+    img = T(det_normal("chk.x", (3, 3, 224, 224)))
+    lab = T(det_labels("chk.lab", (3, 224, 224), 9))
+    grads = []
+    for chk in (False, True):
+        net = N.CSWinTransformer(img_size=224, num_classes=9, embed_dim=64, depth=[1, 2, 2, 1], split_size=[1, 2, 7, 7],
+                                 num_heads=[2, 4, 8, 16], qkv_bias=True, drop_path_rate=0.5, use_chk=chk).to(DEV)
+        fill_state_dict(net).train()
+        torch.manual_seed(77)                               # same Bernoulli draws in both runs
+        logits = net(img)
+        loss, _ = ops.ce_dice_loss(logits, lab)
+        loss.backward()
+        grads.append({n: p.grad.clone() for n, p in net.named_parameters()})
+        if chk:
+            assert any(b._dp_preset for b in net.stage3)     # the factors were pre-drawn and are still there
+    for n in grads[0]:
+        assert torch.allclose(grads[0][n], grads[1][n], rtol=1e-5, atol=1e-7), n
+
+
+def test_out_of_range_label_poisons_the_loss(ops):
+    """nn.CrossEntropyLoss raises on a target outside [0, ncls); the fused loss makes the step's loss NaN instead of silently
+    biasing it (no host sync on the step path)."""
+    logits = T(det_normal("lab.logits", (2, 9, 32, 32)))
+    lab = det_labels("lab.lab", (2, 32, 32), 9).copy()
+    loss, _ = ops.ce_dice_loss(logits, T(lab))
+    assert torch.isfinite(loss)
+    lab[1, 3, 5] = 255
+    loss, _ = ops.ce_dice_loss(logits, T(lab))
+    assert torch.isnan(loss)
+
+
+def test_bf16_wire_pack_unpack():
+    from cswin_unet_amd._lib import call, ptr, stream
+    for n in (4096 * 4, 1000003):
+        x = torch.randn(n + 4, device=DEV)[:n] * 3.0
+        x = x.clone()
+        wire = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+        call("cswin_pack_bf16", ptr(x), ptr(wire), n, stream())
+        assert torch.equal(wire, x.to(torch.bfloat16))
+        back = torch.empty(n, dtype=torch.float32, device=DEV)
+        call("cswin_unpack_bf16", ptr(wire), ptr(back), n, stream())
+        assert torch.equal(back, wire.float())

@@ -11,6 +11,7 @@ import torch
 from oracle.determ import det_normal
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -161,3 +162,20 @@ def test_volume_loop_matches_per_slice_pipeline():
     assert len(m) == 8 and all(0.8 < dice <= 1.0 and h >= 0 for dice, h in m)
     same = predict_volume(image[0], net, (256, 256), device="cpu")  # 2-D input, no resize
     np.testing.assert_array_equal(same, label[0])
+
+
+def test_bench_spawns_its_own_ranks_and_fails_clearly_without_gpus():
+    """`python bench.py --gpus 2` with no launcher environment starts two fresh rank processes itself (the parent never
+    touches the GPU); on a GPU-less box each child must say what it needs instead of dying on an assert."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the devices: the real 2-rank run is tests/test_gpu_multirank.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CSWIN_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    assert r.stderr.count("needs 2 HIP device(s)") == 2, r.stderr
+    assert "rank 0" in r.stderr and "rank 1" in r.stderr
