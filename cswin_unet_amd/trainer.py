@@ -318,6 +318,7 @@ class DataParallelTrainer:
                 # point-to-point links, per-message latency matters more than on a switched fabric.
                 g = eng.flat_grad
                 step = max((hi - lo + self.nbuckets - 1) // self.nbuckets, 1 << 22)      # never below 16 MB per message
+                step = (step + 63) // 64 * 64                                             # buckets start 256-B aligned
                 for o in range(lo, hi, step):
                     chunk = g[o:min(o + step, hi)]
                     if self.allreduce_dtype is None:
