@@ -23,6 +23,9 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 
+// wsgemm.hip: weight-stationary family for plain tall-skinny Linears (returns 1 when the shape is not served there)
+int cswin_ws_gemm(int mode, int epi_mode, const float* A, const float* W, const void* epilogue, int M, int N, int R, void* stream);
+
 namespace {
 
 constexpr int BKMAX = 64;     // largest reduction tile (split sizes are multiples of it)
@@ -617,6 +620,14 @@ int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* 
             else launch_gemm<true, true, 1, EPI_PLAIN, false>(A, B, e, M, N, K, 1, rk, st);
         }
     } else {
+        if (g_matmul_precision == 0) {
+            const int rc = cswin_ws_gemm(0, y_act ? EPI_ACT : (residual ? EPI_RES : EPI_PLAIN), x, w, &e, M, N, K, stream);
+            if (rc < 0) return rc;
+            if (rc == 0) {
+                CSWIN_LAUNCH_CHECK();
+                return CSWIN_OK;
+            }
+        }
         PlainSrc A = {x, K, M, K, nullptr, 1};
         bool vec = (K % 4 == 0) && aligned16(x) && aligned16(w);
         if (y_act) {
@@ -654,6 +665,14 @@ int cswin_linear_bwd_data(const float* dy, const float* w, float* dx, float* dx2
     const int rn = cdiv(N, BKMAX) * BKMAX;
     const int modes = (dx2 != nullptr) + (gelu_pre != nullptr) + (add != nullptr);
     CSWIN_REQUIRE(modes <= 1, CSWIN_ERR_UNSUPPORTED, "linear_bwd_data: dx2 / gelu_pre / add are mutually exclusive");
+    if (!dx2 && g_matmul_precision == 0) {
+        const int rc = cswin_ws_gemm(1, gelu_pre ? EPI_GELUBWD : (add ? EPI_RES : EPI_PLAIN), dy, w, &e, M, K, N, stream);
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            CSWIN_LAUNCH_CHECK();
+            return CSWIN_OK;
+        }
+    }
     if (dx2) {
         if (vec) launch_gemm<true, false, 4, EPI_SPLIT2, false>(A, B, e, M, K, N, 1, rn, st);
         else launch_gemm<true, false, 1, EPI_SPLIT2, false>(A, B, e, M, K, N, 1, rn, st);

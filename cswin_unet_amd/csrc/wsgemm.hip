@@ -1,0 +1,445 @@
+// Weight-stationary fp32 MFMA GEMM for the tall-skinny Linears of CSWin-UNet (gfx950 / CDNA4).
+//
+//   C[m][n] = epilogue( sum_r A[m][r] * Bm(r, n) ),   M = B*L tokens (1e3 .. 1e5),  R and N = 64 .. 1024
+//     forward        (networks/cswin_unet.py:169,177,23-27):  Bm(r, n) = W[n][r]   (W = nn.Linear weight [N][R])
+//     data gradient  (their autograd backward):               Bm(r, n) = W[r][n]   (W = nn.Linear weight [R][N])
+//
+// Every Linear of the model multiplies a long token matrix by a SMALL weight (<= 1 M floats).  The tiled family in gemm.hip
+// re-stages a 64 x 32 slice of the weight together with every 64 x 32 slice of the activations: 16 B of LDS staging per
+// cycle and CU at MFMA peak, a prologue and an epilogue per 64 x 64 tile, and 300 .. 1200 short-lived workgroups per launch.
+// Measured (profiles/round1_notes.md): with the matrix cores made 16x faster the step only gained 17 % -- those kernels
+// are bound by staging, barriers and launch ramps, not by MFMA.  Here the operand roles follow the shape instead:
+//
+//   * one PERSISTENT workgroup per CU (grid <= 256): wave (wn, wk) keeps Bm[wk*KS .. +KS) x [32 wn .. +32) of the weight in
+//     REGISTERS for the whole launch (KS/2 VGPRs: lane (j, h) holds the B operand of every v_mfma_f32_32x32x2_f32 of its
+//     column block), loaded once from L2;
+//   * the workgroup walks its contiguous range of token rows; activations are the only thing that moves: 64 rows x 32 k per
+//     wave-group and step, global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging, no ds_write) into a
+//     3-4 deep ring, XOR-swizzled on the SOURCE address so that the ds_read_b128 A fragments are bank-conflict free;
+//   * one raw s_barrier per step with a counted s_waitcnt vmcnt (the DMA of the next stages stays in flight across it);
+//   * k-groups (wk) sum their accumulators through LDS once per 64-row tile; the epilogue is gemm_epilogue.h's.
+// Activation staging drops to 2-4 B per cycle and CU, the weight is read once per CU, and the MFMA stream of a wave is
+// 32 back-to-back instructions per step between two barriers.
+#include <stdlib.h>
+
+#include "gemm_epilogue.h"
+
+namespace {
+
+constexpr int WS_BM = 64;            // rows per tile (two 32-row MFMA blocks)
+constexpr int WS_BK = 32;            // k per step and k-group
+constexpr int WS_STAGE_FLOATS = WS_BM * WS_BK;   // one k-group's stage: 8 KB
+
+struct WsParams {
+    const float* A; long lda;        // [M][R]
+    const float* W; long ldw;        // forward: [N][R]; data gradient: [R][N]
+    int M, N, R;
+    int n_groups, slots;             // grid = n_groups * slots
+    long long* stamps;               // debug (cswin_debug_set_ws_stamps): [workgroup][16] s_memtime stamps of wave 0, or NULL
+    Epilogue epi;
+};
+
+#define WS_STAMP(k)                                                                                             \
+    do {                                                                                                        \
+        if (p.stamps && threadIdx.x == 0 && (k) < 16) p.stamps[(long)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
+// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to lds_dst + 16 * lane (wave-uniform lds_dst).  hipcc does not
+// count this load: completion is tracked by hand with ws_wait_vmcnt (guide 5.7).
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// ring depth: 8-wave workgroups own the CU's LDS (<= 133 KB); two 4-wave workgroups per CU get <= 80 KB each
+constexpr int ws_ring_depth(int nwn, int nwk) { return nwn * nwk == 4 ? (nwk >= 2 ? 3 : 4) : (nwk >= 4 ? 3 : 4); }
+
+template <int N>
+__device__ __forceinline__ void ws_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void ws_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+
+// Epilogue operands of one 64 x 32 wave tile in the store layout (lane: row rrow + 8 p of block i, columns rcol .. rcol + 3).
+// They are loaded at the top of the tile's LAST step, retired together with the LDS-DMA by one explicit vmcnt(0) after that
+// step's MFMAs, and only then consumed: inside the tile loop hipcc never sees a load whose result is still pending, so its
+// s_waitcnt pass inserts no vmcnt(0) of its own (it would drain the stores of the tile and every DMA in flight).
+template <int EPI>
+struct WsEpiRegs {
+    static constexpr bool HAS_AUX = EPI == EPI_RES || EPI == EPI_GELUBWD;
+    f32x4 aux[HAS_AUX ? 2 : 1][HAS_AUX ? 4 : 1];
+    float rs[2][4];
+};
+
+template <int EPI>
+__device__ __forceinline__ void ws_epi_prefetch(WsEpiRegs<EPI>& r, const Epilogue& e, int M, int N, int mb, int nb, int lane, bool full) {
+    const int rrow = lane >> 3, n = nb + (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int m = mb + i * 32 + rrow + 8 * p;
+            const bool ok = m < M && n < N && (i == 0 || full);
+            r.rs[i][p] = (e.row_scale && ok) ? e.row_scale[m / e.rows_per_sample] : 1.0f;
+            if constexpr (WsEpiRegs<EPI>::HAS_AUX) {
+                const float* ap = EPI == EPI_RES ? e.residual : e.gelu_pre;
+                const long ld = EPI == EPI_RES ? e.ldres : e.ldpre;
+                r.aux[i][p] = ok ? *reinterpret_cast<const f32x4*>(ap + (long)m * ld + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+}
+
+// acc (native MFMA C/D layout) -> wave-private LDS patch -> 16-B stores; the arithmetic of gemm_epilogue.h's vector path
+template <int EPI>
+__device__ __forceinline__ void ws_epi_store(const WsEpiRegs<EPI>& r, const Epilogue& e, f32x16 (&acc)[2][1], f32x4 bias_v, int M, int N,
+                                             int mb, int nb, int lane, float* wbuf, bool full) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int rrow = lane >> 3, rcol = (lane & 7) * 4;
+    const int n = nb + rcol;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i == 1 && !full) break;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) wbuf[((g & 3) + 8 * (g >> 2) + 4 * lh) * EP_LD + li] = acc[i][0][g];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int m = mb + i * 32 + rrow + 8 * p;
+            f32x4 o = *reinterpret_cast<const f32x4*>(&wbuf[(rrow + 8 * p) * EP_LD + rcol]) + bias_v;
+            if (EPI == EPI_GELUBWD) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] *= gelu_grad_f(r.aux[i][p][c]);
+            }
+            o *= r.rs[i][p];
+            if (EPI == EPI_RES) o += r.aux[i][p];
+            if (m < M && n < N) {
+                *reinterpret_cast<f32x4*>(e.C + (long)m * e.ldc + n) = o;
+                if (EPI == EPI_ACT) {
+                    f32x4 a;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a[c] = gelu_f(o[c]);
+                    *reinterpret_cast<f32x4*>(e.Cact + (long)m * e.ldact + n) = a;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int KS, int NWN, int NWK, bool BTRANS, int EPI>
+__global__ __launch_bounds__(64 * NWN * NWK, 2) void ws_gemm_kernel(WsParams p) {      // 8 waves per CU: one workgroup of 8 or two of 4
+    constexpr int NWAVES = NWN * NWK;
+    constexpr int NKC = KS / WS_BK;                       // steps per tile
+    constexpr int D = ws_ring_depth(NWN, NWK);            // ring depth
+    constexpr int Q = 8 / NWN;                            // LDS-DMA instructions per wave and stage (8 per k-group)
+    constexpr int STAGE = NWK * WS_STAGE_FLOATS;
+    constexpr int PATCH = 2 * 16 * 64;                    // one wave's two accumulator blocks in native layout
+    constexpr int RED = NWK > 1 ? (NWK / 2) * NWN * PATCH : 0;
+    constexpr int EPIW = NWAVES * EP_WAVE_FLOATS;
+    constexpr int SCRATCH = RED > EPIW ? RED : EPIW;
+    static_assert(KS % WS_BK == 0 && 8 % NWN == 0 && NWAVES % 4 == 0, "unsupported wave layout");
+    extern __shared__ __attribute__((aligned(1024))) float lds[];   // [D][NWK][64][32] ring | scratch
+    float* scratch = lds + D * STAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % NWN, wk = wave / NWN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // XCD-aware order: blocks b, b + 8, ... share an XCD (private L2).  Consecutive logical ids = the n-groups of one row
+    // range, so the activations of a row range are fetched into one L2 only.
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
+    const int lb = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int slot = lb / p.n_groups, ng = lb - slot * p.n_groups;
+    const int units = (p.M + 31) >> 5;
+    const int u0 = (int)((long)slot * units / p.slots), u1 = (int)((long)(slot + 1) * units / p.slots);
+    const int n_units = u1 - u0;
+    const int ntiles = (n_units + 1) >> 1;
+    const int total = ntiles * NKC;
+    const int row_base = u0 * 32;
+    const int row_end = min(p.M, u1 * 32);               // rows this workgroup owns
+    const int ncol0 = (ng * NWN + wn) * 32;               // this wave's output columns
+    const bool active = ncol0 < p.N;                       // wave-uniform
+
+    WS_STAMP(0);
+    // ---- the weight slice of this wave -> registers: breg[4 * (koff / 8) + s] = Bm(wk*KS + koff + 4 lh + s, ncol0 + li) ----
+    float breg[KS / 2];
+    {
+        const int n = ncol0 + li;
+        const bool nok = n < p.N;
+        if constexpr (!BTRANS) {
+            const float* wrow = p.W + (long)(nok ? n : 0) * p.ldw + wk * KS + 4 * lh;
+#pragma unroll
+            for (int g = 0; g < KS / 8; ++g) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(wrow + 8 * g);
+                if (!nok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) breg[4 * g + s] = v[s];
+            }
+        } else {
+            const float* wcol = p.W + (long)(wk * KS + 4 * lh) * p.ldw + (nok ? n : 0);
+#pragma unroll
+            for (int g = 0; g < KS / 8; ++g)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float v = wcol[(long)(8 * g + s) * p.ldw];
+                    breg[4 * g + s] = nok ? v : 0.f;
+                }
+        }
+    }
+
+    // ---- LDS-DMA geometry: instruction q of this wave covers k-group gq, rows 8*rb .. +8 of the tile (8 lanes x 16 B per row) ----
+    // lane -> (row = 8 rb + lane/8, physical chunk pc = lane & 7) holds logical chunk pc ^ ((row >> 1) & 7) of that row
+    int q_row[Q];
+    int q_off[Q];
+    unsigned q_lds[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int i = wave * Q + q;                       // 0 .. 8 NWK - 1
+        const int gq = i >> 3, rb = i & 7;
+        const int row = 8 * rb + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        q_row[q] = row;
+        q_off[q] = gq * KS + 4 * c;
+        q_lds[q] = (unsigned)(i * 1024);                  // byte offset of the 1 KB piece inside a stage
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;   // LDS byte address of the ring
+
+    auto issue = [&](int s) {                              // LDS-DMA of step s into stage s % D
+        const int tile = s / NKC, kc = s - tile * NKC;
+        const unsigned dst = lds_base + (unsigned)((s % D) * STAGE * 4);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            int m = row_base + tile * WS_BM + q_row[q];
+            m = m < p.M ? m : p.M - 1;                     // rows past the end re-read the last row (masked in the epilogue)
+            glds16(p.A + (long)m * p.lda + q_off[q] + kc * WS_BK, __builtin_amdgcn_readfirstlane(dst + q_lds[q]));
+        }
+    };
+
+    // read-side address of this lane inside a stage: row-half hm, k-offset kk (0, 8, 16, 24)
+    const int sw = (li >> 1) & 7;                          // (row >> 1) & 7 with row = 32 hm + li: hm adds 16 -> same low bits
+    auto a_frag = [&](const float* st, int hm, int kk) -> f32x4 {
+        const int pc = ((kk >> 2) + lh) ^ sw;
+        return *reinterpret_cast<const f32x4*>(st + wk * WS_STAGE_FLOATS + (32 * hm + li) * WS_BK + 4 * pc);
+    };
+
+    // bias of this wave's columns in the epilogue's lane layout (lane owns columns ncol0 + 4 (lane & 7) .. +3): loaded once
+    f32x4 bias_v = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int n = ncol0 + (lane & 7) * 4;
+        if (p.epi.bias && n < p.N) bias_v = *reinterpret_cast<const f32x4*>(p.epi.bias + n);
+    }
+    if (total > 0) {
+#pragma unroll
+        for (int s = 0; s < D - 1; ++s)
+            if (s < total) issue(s);
+    }
+    // Everything hipcc knows to be in flight (weight and bias loads) is retired HERE, so that its s_waitcnt pass has nothing
+    // pending at the loop header: otherwise it drains vmcnt(0) -- stores and LDS-DMA included -- at the top of every tile.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): also covers the DMA of the first D - 1 stages
+    WS_STAMP(1);
+    ws_barrier();                                          // step 0 has landed for every wave
+    WS_STAMP(2);
+
+    // Step protocol (one barrier per step): issue the DMA of step s + D - 1 into the stage that step s - 1 just released ->
+    // MFMAs of step s -> wait for MY DMA of step s + 1 (counted: the later stages stay in flight) -> [tile end: epilogue]
+    // -> barrier.  The wait sits BEFORE the epilogue's stores: vmcnt retires in issue order, so a counted wait behind
+    // freshly issued stores would wait for them too.
+    int s = 0;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const bool full = 2 * tile + 1 < n_units;          // second 32-row block belongs to this workgroup
+        f32x16 acc[2][1];
+        WsEpiRegs<EPI> er;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][0][e] = acc[1][0][e] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc, ++s) {
+            {
+                int si = s + D - 1;                        // laundered: keeps hipcc from specialising (and hoisting) the DMA
+                asm volatile("" : "+s"(si));               // addresses of every unrolled step
+                if (si < total) issue(si);
+            }
+            if (kc == NKC - 1 && wk == 0 && active)
+                ws_epi_prefetch<EPI>(er, p.epi, row_end, p.N, row_base + tile * WS_BM, ncol0, lane, full);
+            if (active) {
+                const float* st = lds + (s % D) * STAGE;
+#pragma unroll
+                for (int hm = 0; hm < 2; ++hm) {
+                    if (hm == 1 && !full) break;
+                    f32x4 af[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) af[kk] = a_frag(st, hm, 8 * kk);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[hm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][e], breg[kc * 16 + kk * 4 + e], acc[hm][0], 0, 0, 0);
+                }
+            }
+            // my DMA of step s + 1 has landed once at most the (D - 2) later stages are outstanding.  The tile's last step
+            // retires everything instead (the epilogue operands just loaded sit behind the DMA in the in-order counter).
+            if (kc == NKC - 1) __builtin_amdgcn_s_waitcnt(0x0F70);
+            else if (s + D - 1 < total) ws_wait_vmcnt<(D - 2) * Q>();
+            else ws_wait_vmcnt<0>();
+            if (kc + 1 < NKC) ws_barrier();                // (the tile's last barrier comes after the epilogue)
+        }
+        WS_STAMP(3 + 2 * tile);
+        // ---- k-groups -> one accumulator (binary tree through LDS, native C/D layout) ----
+        if constexpr (NWK > 1) {
+#pragma unroll
+            for (int half = NWK / 2; half >= 1; half >>= 1) {
+                if (wk >= half && wk < 2 * half) {
+                    float* dst = scratch + ((wk - half) * NWN + wn) * PATCH + lane;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) dst[(i * 16 + g) * 64] = acc[i][0][g];
+                }
+                ws_barrier();
+                if (wk < half) {
+                    const float* src = scratch + (wk * NWN + wn) * PATCH + lane;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) acc[i][0][g] += src[(i * 16 + g) * 64];
+                }
+                ws_barrier();
+            }
+        }
+        if (wk == 0 && active)
+            ws_epi_store<EPI>(er, p.epi, acc, bias_v, row_end, p.N, row_base + tile * WS_BM, ncol0, lane, scratch + wave * EP_WAVE_FLOATS, full);
+        WS_STAMP(4 + 2 * tile);
+        ws_barrier();
+    }
+    WS_STAMP(15);
+}
+
+template <int KS, int NWN, int NWK>
+constexpr size_t ws_lds_bytes() {
+    constexpr int D = ws_ring_depth(NWN, NWK);
+    constexpr int RED = NWK > 1 ? (NWK / 2) * NWN * 2 * 16 * 64 : 0;
+    constexpr int EPIW = NWN * NWK * EP_WAVE_FLOATS;
+    return (size_t)(D * NWK * WS_STAGE_FLOATS + (RED > EPIW ? RED : EPIW)) * sizeof(float);
+}
+
+template <int KS, int NWN, int NWK, bool BTRANS, int EPI>
+int ws_launch(const WsParams& p, hipStream_t st) {
+    constexpr size_t lds = ws_lds_bytes<KS, NWN, NWK>();
+    auto kern = ws_gemm_kernel<KS, NWN, NWK, BTRANS, EPI>;
+    static bool reserved = false;       // one-time, idempotent (not a stream operation: stays out of graph captures)
+    if (!reserved) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { cswin_set_error("ws_gemm: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return CSWIN_ERR_HIP; }
+        reserved = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.n_groups * p.slots), dim3(64 * NWN * NWK), lds, st, p);
+    return CSWIN_OK;
+}
+
+struct WsCfg { int ks, nwn, nwk; double cost; };
+
+// Cost model (cycles; constants from in-kernel stamps, tools/ws_stamps.py): the launch ends with the most loaded workgroup.
+// A workgroup of n units (32 rows) runs n * KS/2 MFMAs of 64 cycles per wave, two waves per SIMD; every 64-row tile pays one
+// epilogue (~3000 cycles, not overlapped: the waves of a workgroup move in lock-step); the weight load and the first DMA
+// cost ~6000 cycles.  Layouts whose register allocation spills (hipcc -Rpass-analysis=kernel-resource-usage) are left out.
+bool ws_choose(int M, int N, int R, bool aux, WsCfg* out) {
+    static const int ks_list[] = {64, 128, 192, 256};
+    static const int lay[][2] = {{8, 1}, {4, 2}, {2, 4}, {4, 1}, {2, 2}};
+    const int units = (M + 31) / 32;
+    bool found = false;
+    WsCfg best = {0, 0, 0, 1e300};
+    for (int ks : ks_list)
+        for (auto& l : lay) {
+            const int nwn = l[0], nwk = l[1];
+            if (ks * nwk != R) continue;
+            if ((nwk == 4 && ks == 256) || (nwn == 2 && nwk == 2 && ks == 256)) continue;                  // spill
+            if (aux && ((nwk == 4 && ks >= 192) || (nwk == 2 && ks == 256))) continue;                      // spill
+            const int ng = (N + 32 * nwn - 1) / (32 * nwn);
+            const int wgs = nwn * nwk == 4 ? 512 : 256;           // two 4-wave workgroups per CU, or one of 8
+            if (ng > wgs) continue;
+            int slots = wgs / ng;
+            if (slots > units) slots = units;
+            if (slots < 1) continue;
+            const int upw = (units + slots - 1) / slots;
+            const double cost = (double)upw * (ks / 2) * 128.0 + ((upw + 1) / 2) * (3000.0 + (nwk > 1 ? 800.0 * nwk : 0.0)) + 6000.0;
+            if (cost < best.cost) { best = {ks, nwn, nwk, cost}; found = true; }
+        }
+    if (found) *out = best;
+    return found;
+}
+
+template <bool BTRANS, int EPI>
+int ws_dispatch(const WsCfg& c, WsParams& p, hipStream_t st) {
+    const int ng = (p.N + 32 * c.nwn - 1) / (32 * c.nwn);
+    const int units = (p.M + 31) / 32;
+    int slots = (c.nwn * c.nwk == 4 ? 512 : 256) / ng;
+    if (slots > units) slots = units;
+    p.n_groups = ng;
+    p.slots = slots;
+#define WS_CASE(KS_, NWN_, NWK_) \
+    if (c.ks == KS_ && c.nwn == NWN_ && c.nwk == NWK_) return ws_launch<KS_, NWN_, NWK_, BTRANS, EPI>(p, st);
+    WS_CASE(64, 8, 1) WS_CASE(128, 8, 1) WS_CASE(192, 8, 1) WS_CASE(256, 8, 1)
+    WS_CASE(64, 4, 2) WS_CASE(128, 4, 2) WS_CASE(192, 4, 2) WS_CASE(256, 4, 2)
+    WS_CASE(64, 2, 4) WS_CASE(128, 2, 4) WS_CASE(192, 2, 4) WS_CASE(256, 2, 4)
+    WS_CASE(64, 4, 1) WS_CASE(128, 4, 1) WS_CASE(192, 4, 1) WS_CASE(256, 4, 1)
+    WS_CASE(64, 2, 2) WS_CASE(128, 2, 2) WS_CASE(192, 2, 2) WS_CASE(256, 2, 2)
+#undef WS_CASE
+    return 1;
+}
+
+}  // namespace
+
+// Entry used by gemm.hip's cswin_linear_fwd / cswin_linear_bwd_data (internal: not part of the C ABI).
+// Returns 1 when the shape is not served here (the caller falls back to the tiled family), 0 on launch, < 0 on error.
+// mode: 0 = forward (W [N][R]), 1 = data gradient (W [R][N]).  epi_mode: EPI_PLAIN / EPI_ACT / EPI_RES / EPI_GELUBWD.
+static long long* g_ws_stamps = nullptr;
+extern "C" void cswin_debug_set_ws_stamps(void* p) { g_ws_stamps = (long long*)p; }
+static int g_ws_enabled = -1;       // debug / tuning aid only (cswin_debug_set_ws_gemm): A/B the two families in one process
+extern "C" void cswin_debug_set_ws_gemm(int on) { g_ws_enabled = on; }
+
+int cswin_ws_gemm(int mode, int epi_mode, const float* A, const float* W, const void* epilogue, int M, int N, int R, void* stream) {
+    // Opt-in (CSWIN_WS_GEMM=1 / cswin_debug_set_ws_gemm): on the model's shapes this family ties the tiled one within +-10 %
+    // (profiles/round2_notes.md, "Weight-stationary GEMM"), so the default path stays the tiled family.
+    if (g_ws_enabled < 0) g_ws_enabled = getenv("CSWIN_WS_GEMM") ? atoi(getenv("CSWIN_WS_GEMM")) != 0 : 0;
+    if (!g_ws_enabled) return 1;
+    if (M < 512 || N % 4 != 0 || R % 4 != 0 || !aligned16(A) || !aligned16(W)) return 1;
+    WsCfg c;
+    if (!ws_choose(M, N, R, epi_mode == EPI_RES || epi_mode == EPI_GELUBWD, &c)) return 1;
+    if (const char* f = getenv("CSWIN_WS_LAYOUT")) {        // tuning aid: "nwn,nwk" forces a wave layout where it fits R
+        int a = 0, b = 0;
+        if (sscanf(f, "%d,%d", &a, &b) == 2 && b > 0 && R % b == 0) {
+            const int ks = R / b;
+            if (ks == 64 || ks == 128 || ks == 192 || ks == 256) c = WsCfg{ks, a, b, 0.0};
+            else return 1;
+        }
+    }
+    WsParams p = {};
+    p.A = A; p.lda = R;
+    p.W = W; p.ldw = mode == 0 ? R : N;
+    p.M = M; p.N = N; p.R = R;
+    p.stamps = g_ws_stamps;
+    p.epi = *(const Epilogue*)epilogue;
+    p.epi.vec_store = epilogue_vec_ok(p.epi, N);
+    if (!p.epi.vec_store) return 1;                    // the persistent kernel compiles the 16-B epilogue only
+    hipStream_t st = (hipStream_t)stream;
+    int rc = 1;
+    if (mode == 0) {
+        if (epi_mode == EPI_PLAIN) rc = ws_dispatch<false, EPI_PLAIN>(c, p, st);
+        else if (epi_mode == EPI_ACT) rc = ws_dispatch<false, EPI_ACT>(c, p, st);
+        else if (epi_mode == EPI_RES) rc = ws_dispatch<false, EPI_RES>(c, p, st);
+    } else {
+        if (epi_mode == EPI_PLAIN) rc = ws_dispatch<true, EPI_PLAIN>(c, p, st);
+        else if (epi_mode == EPI_GELUBWD) rc = ws_dispatch<true, EPI_GELUBWD>(c, p, st);
+        else if (epi_mode == EPI_RES) rc = ws_dispatch<true, EPI_RES>(c, p, st);
+    }
+    return rc;
+}
