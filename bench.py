@@ -191,7 +191,7 @@ def _spawn_ranks(n, argv):
         # rank 0 inherits stdout (the one JSON line); the other ranks' stdout goes to stderr
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else sys.stderr))
-    rc = 0
+    rc, deadline = 0, None
     try:
         pending = list(procs)
         while pending:
@@ -200,10 +200,13 @@ def _spawn_ranks(n, argv):
                 if code is None:
                     continue
                 pending.remove(p)
-                if code != 0:
-                    rc = rc or code
-                    for q in pending:                    # a dead rank leaves the others blocked in a collective
-                        q.terminate()
+                if code != 0 and rc == 0:
+                    rc = code
+                    deadline = time.time() + 20.0        # the other ranks get 20 s to fail (and say why) by themselves ...
+            if deadline is not None and time.time() > deadline:
+                for q in pending:                        # ... then they are blocked in a collective on the dead rank
+                    q.terminate()
+                deadline = time.time() + 1e9
             time.sleep(0.2)
     finally:
         for p in procs:

@@ -49,9 +49,10 @@ SIGNATURES = {
     "cswin_carafe_bwd_workspace": (SZ, [I, I, I, I, I]),
     "cswin_carafe_bwd": (I, [P, P, P, P, P, P, P, SZ, I, I, I, I, I, P]),
     "cswin_loss_workspace": (SZ, [I, I, L]),
-    "cswin_loss_sums": (I, [P, P, P, P, SZ, I, I, L, P]),
-    "cswin_loss_finalize": (I, [P, P, P, D, I, F, F, P]),
-    "cswin_loss_bwd": (I, [P, P, P, P, P, F, F, I, I, L, P]),
+    "cswin_loss_sums": (I, [P, P, P, P, SZ, I, I, L, I, P]),
+    "cswin_loss_finalize": (I, [P, P, P, D, I, F, F, P, P]),
+    "cswin_loss_bwd": (I, [P, P, P, P, P, F, F, I, I, L, I, P]),
+    "cswin_dropout": (I, [P, P, P, P, L, L, F, ctypes.c_ulonglong, P]),
     "cswin_sgd_flat": (I, [P, P, P, L, P, F, F, F, P]),
     "cswin_multi_copy": (I, [P, I, P]),
     "cswin_pack_bf16": (I, [P, P, L, P]),

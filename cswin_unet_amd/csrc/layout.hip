@@ -80,9 +80,50 @@ int grid1d(long total) {
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
+// ---- dropout -------------------------------------------------------------------------------------------------------------
+// counter-based generator: two rounds of a 64-bit mix (splitmix64 finaliser) of (seed, element index / 4); each 64-bit result
+// gives the four 16-bit uniforms of a 16-B chunk.  Stateless, so backward regenerates the forward mask exactly.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, const float* __restrict__ residual,
+                                                       const float* __restrict__ row_scale, float* __restrict__ y, long n,
+                                                       long elems_per_sample, float p, unsigned long long seed) {
+    const unsigned thr = (unsigned)(p * 65536.0f);             // keep iff u16 >= thr  (P(drop) = thr / 65536)
+    const float inv_keep = 1.0f / (1.0f - p);
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const unsigned long long r = mix64(mix64(seed) ^ (unsigned long long)i);
+        const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+        f32x4 o = residual ? reinterpret_cast<const f32x4*>(residual)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float rs = (row_scale ? row_scale[(4 * i) / elems_per_sample] : 1.0f) * inv_keep;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += (((unsigned)(r >> (16 * e)) & 0xFFFFu) >= thr) ? rs * xv[e] : 0.f;
+        reinterpret_cast<f32x4*>(y)[i] = o;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int cswin_dropout(const float* x, const float* residual, const float* row_scale, float* y, long n, long elems_per_sample,
+                  float p, unsigned long long seed, void* stream) {
+    CSWIN_REQUIRE(x && y && n > 0 && n % 4 == 0 && elems_per_sample > 0 && elems_per_sample % 4 == 0, CSWIN_ERR_SHAPE,
+                  "dropout: n and elems_per_sample must be positive multiples of 4");
+    CSWIN_REQUIRE(p >= 0.f && p < 1.f, CSWIN_ERR_SHAPE, "dropout: p = %f outside [0, 1)", p);
+    CSWIN_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)residual)) & 15) == 0, CSWIN_ERR_ALIGN, "dropout: 16-B alignment required");
+    long b = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(dropout_kernel, dim3((int)(b > 8192 ? 8192 : b)), dim3(256), 0, (hipStream_t)stream, x, residual, row_scale, y, n,
+                       elems_per_sample, p, seed);
+    CSWIN_LAUNCH_CHECK();
+    return CSWIN_OK;
+}
+
 
 int cswin_nchw_to_tokens(const float* x, float* y, int B, int C, int H, int W, int Cpad, void* stream) {
     CSWIN_REQUIRE(x && y && B > 0 && C > 0 && Cpad >= C && H > 0 && W > 0, CSWIN_ERR_SHAPE, "nchw_to_tokens: bad arguments");

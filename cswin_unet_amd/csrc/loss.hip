@@ -9,7 +9,8 @@
 namespace {
 
 // sums layout: [0] = sum over pixels of -log p[label];  [1 + c] = intersect_c;  [1 + ncls + c] = y_sum_c;  [1 + 2 ncls + c] = z_sum_c
-template <int NC>
+// PROBS: the input already holds class probabilities (DiceLoss(..., softmax=False), utils.py:32-34): no softmax here
+template <int NC, bool PROBS>
 __global__ __launch_bounds__(256) void loss_sums_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
                                                          float* __restrict__ partial, int B, long HW) {
     constexpr int NV = 1 + 3 * NC;
@@ -31,10 +32,10 @@ __global__ __launch_bounds__(256) void loss_sums_kernel(const float* __restrict_
         float sum = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            v[c] = __expf(v[c] - mx);
+            if (!PROBS) v[c] = __expf(v[c] - mx);
             sum += v[c];
         }
-        const float inv = 1.0f / sum;
+        const float inv = PROBS ? 1.0f : 1.0f / sum;
         const int lab = (int)labels[i];
         // nn.CrossEntropyLoss raises on a target outside [0, ncls) (trainer.py:40,55); without a host sync the device-side
         // equivalent is to poison the CE sum: the step's loss reads NaN instead of a silently biased value
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void loss_sums_kernel(const float* __restrict_
 
 // out[0..2] = loss, ce, dice;  coef[c] = a_c, coef[ncls + c] = b_c with d dice_c / d p_c(pixel) = a_c * onehot + b_c * p
 __global__ void loss_finalize_kernel(const float* __restrict__ sums, float* __restrict__ out, float* __restrict__ coef,
-                                     float n_pixels, int ncls, float w_ce, float w_dice) {
+                                     float n_pixels, int ncls, float w_ce, float w_dice, const float* __restrict__ class_weight) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const float smooth = 1e-5f;
     const float ce = sums[0] / n_pixels;
@@ -70,9 +71,10 @@ __global__ void loss_finalize_kernel(const float* __restrict__ sums, float* __re
     for (int c = 0; c < ncls; ++c) {
         const float I = sums[1 + c], Y = sums[1 + ncls + c], Z = sums[1 + 2 * ncls + c];
         const float D = Z + Y + smooth;
-        dice += 1.f - (2.f * I + smooth) / D;
-        coef[c] = -2.f / D;
-        coef[ncls + c] = 2.f * (2.f * I + smooth) / (D * D);
+        const float wc = class_weight ? class_weight[c] : 1.f;          // utils.py:44: loss += dice * weight[i]
+        dice += wc * (1.f - (2.f * I + smooth) / D);
+        coef[c] = wc * -2.f / D;
+        coef[ncls + c] = wc * 2.f * (2.f * I + smooth) / (D * D);
     }
     dice /= ncls;
     out[0] = w_ce * ce + w_dice * dice;
@@ -81,7 +83,7 @@ __global__ void loss_finalize_kernel(const float* __restrict__ sums, float* __re
 }
 
 // dlogits = gout * [ ce_scale * (p - onehot) + dice_scale * p_c * (G_c - sum_j p_j G_j) ],  G_c = a_c onehot_c + b_c p_c
-template <int NC>
+template <int NC, bool PROBS>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
                                                         const float* __restrict__ coef, const float* __restrict__ gout,
                                                         float* __restrict__ dlogits, float ce_scale, float dice_scale,
@@ -107,10 +109,10 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
         float sum = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            v[c] = __expf(v[c] - mx);
+            if (!PROBS) v[c] = __expf(v[c] - mx);
             sum += v[c];
         }
-        const float inv = 1.0f / sum;
+        const float inv = PROBS ? 1.0f : 1.0f / sum;
         const int lab = (int)labels[i];
         float G[NC], dot = 0.f;
 #pragma unroll
@@ -123,7 +125,8 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const float oh = (c == lab) ? 1.f : 0.f;
-            dp[c * HW] = g * (ce_scale * (v[c] - oh) + dice_scale * v[c] * (G[c] - dot));
+            if (PROBS) dp[c * HW] = g * dice_scale * G[c];              // d/dp directly: no softmax Jacobian (CE is not defined on probabilities here)
+            else dp[c * HW] = g * (ce_scale * (v[c] - oh) + dice_scale * v[c] * (G[c] - dot));
         }
     }
 }
@@ -156,12 +159,16 @@ size_t cswin_loss_workspace(int B, int ncls, long HW) { return (size_t)loss_bloc
 
 // logits (B, ncls, HW) fp32, labels (B, HW) int64 -> sums[1 + 3*ncls] (local batch)
 int cswin_loss_sums(const float* logits, const long long* labels, float* sums, void* workspace, size_t ws_bytes, int B,
-                    int ncls, long HW, void* stream) {
+                    int ncls, long HW, int inputs_are_probs, void* stream) {
     CSWIN_REQUIRE(logits && labels && sums && B > 0 && HW > 0, CSWIN_ERR_SHAPE, "loss_sums: bad arguments");
     CSWIN_REQUIRE(workspace && ws_bytes >= cswin_loss_workspace(B, ncls, HW), CSWIN_ERR_WORKSPACE, "loss_sums: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const int nblk = loss_blocks((long)B * HW);
-    NC_SWITCH(ncls, hipLaunchKernelGGL(loss_sums_kernel<NC>, dim3(nblk), dim3(256), 0, st, logits, labels, (float*)workspace, B, HW));
+    if (inputs_are_probs) {
+        NC_SWITCH(ncls, hipLaunchKernelGGL((loss_sums_kernel<NC, true>), dim3(nblk), dim3(256), 0, st, logits, labels, (float*)workspace, B, HW));
+    } else {
+        NC_SWITCH(ncls, hipLaunchKernelGGL((loss_sums_kernel<NC, false>), dim3(nblk), dim3(256), 0, st, logits, labels, (float*)workspace, B, HW));
+    }
     CSWIN_LAUNCH_CHECK();
     launch_rows_sum((const float*)workspace, sums, nullptr, 0, 1 + 3 * ncls, nblk, 1 + 3 * ncls, st);
     CSWIN_LAUNCH_CHECK();
@@ -170,20 +177,24 @@ int cswin_loss_sums(const float* logits, const long long* labels, float* sums, v
 
 // sums (possibly all-reduced) -> out[3] = {loss, ce, dice}, coef[2*ncls]; n_pixels = pixel count the sums cover
 int cswin_loss_finalize(const float* sums, float* out, float* coef, double n_pixels, int ncls, float w_ce, float w_dice,
-                        void* stream) {
+                        const float* class_weight, void* stream) {
     CSWIN_REQUIRE(sums && out && coef && n_pixels > 0 && ncls > 0, CSWIN_ERR_SHAPE, "loss_finalize: bad arguments");
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, out, coef, (float)n_pixels, ncls, w_ce, w_dice);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, out, coef, (float)n_pixels, ncls, w_ce, w_dice, class_weight);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }
 
 // ce_scale = w_ce / n_pixels ; dice_scale = w_dice / ncls (times world size under gradient averaging)
 int cswin_loss_bwd(const float* logits, const long long* labels, const float* coef, const float* grad_out, float* dlogits,
-                   float ce_scale, float dice_scale, int B, int ncls, long HW, void* stream) {
+                   float ce_scale, float dice_scale, int B, int ncls, long HW, int inputs_are_probs, void* stream) {
     CSWIN_REQUIRE(logits && labels && coef && dlogits && B > 0 && HW > 0, CSWIN_ERR_SHAPE, "loss_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int nblk = loss_blocks((long)B * HW) * 4;
-    NC_SWITCH(ncls, hipLaunchKernelGGL(loss_bwd_kernel<NC>, dim3(nblk), dim3(256), 0, st, logits, labels, coef, grad_out, dlogits, ce_scale, dice_scale, B, HW));
+    if (inputs_are_probs) {
+        NC_SWITCH(ncls, hipLaunchKernelGGL((loss_bwd_kernel<NC, true>), dim3(nblk), dim3(256), 0, st, logits, labels, coef, grad_out, dlogits, ce_scale, dice_scale, B, HW));
+    } else {
+        NC_SWITCH(ncls, hipLaunchKernelGGL((loss_bwd_kernel<NC, false>), dim3(nblk), dim3(256), 0, st, logits, labels, coef, grad_out, dlogits, ce_scale, dice_scale, B, HW));
+    }
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }

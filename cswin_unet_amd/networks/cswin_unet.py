@@ -49,9 +49,8 @@ class Mlp(nn.Module):
             raise NotImplementedError("the HIP Mlp kernel fuses the exact (erf) GELU only")
 
     def forward(self, x, residual=None, row_scale=None):
-        if self.drop.p > 0 and self.training:
-            raise NotImplementedError("Mlp dropout p > 0 is not implemented on the HIP path (reference uses 0)")
-        return ops.mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, residual, row_scale)
+        p = self.drop.p if self.training else 0.0
+        return ops.mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, residual, row_scale, drop_p=p)
 
 
 class LePEAttention(nn.Module):
@@ -76,7 +75,9 @@ class LePEAttention(nn.Module):
         if q.shape[1] != self.resolution * self.resolution:
             raise AssertionError("flatten img_tokens has wrong size")
         if self.attn_drop.p > 0 and self.training:
-            raise NotImplementedError("attention dropout p > 0 is not implemented on the HIP path (reference uses 0)")
+            # the softmax matrix never exists outside the fused kernel's registers; a mask on it is not built (reference
+            # configs and every yaml of the repo use attn_drop_rate 0)
+            raise NotImplementedError("attention-probability dropout (attn_drop_rate > 0) is not implemented in the fused stripe-attention kernel")
         packed = torch.cat([q, k, v], dim=-1)
         return ops.stripe_attention(packed, self.resolution, self.split_size, [self.idx], [self.num_heads],
                                     [self.get_v.weight], [self.get_v.bias], self.scale)
@@ -122,14 +123,21 @@ class CSWinBlock(nn.Module):
         B, L, C = x.shape
         if L != self.patches_resolution ** 2:
             raise AssertionError("flatten img_tokens has wrong size")
-        if self.proj_drop.p > 0 and self.training:
-            raise NotImplementedError("proj dropout p > 0 is not implemented on the HIP path (reference uses 0)")
         a = self.attns
-        if self.mlp.drop.p > 0 and self.training:
-            raise NotImplementedError("Mlp dropout p > 0 is not implemented on the HIP path (reference uses 0)")
+        if a[0].attn_drop.p > 0 and self.training:
+            raise NotImplementedError("attention-probability dropout (attn_drop_rate > 0) is not implemented in the fused stripe-attention kernel")
         if type(self.norm1) is not nn.LayerNorm or type(self.norm2) is not nn.LayerNorm:
             raise NotImplementedError("the HIP block fuses nn.LayerNorm only")
         rs1, rs2 = self._keep_scales(x)
+        if self.training and (self.proj_drop.p > 0 or self.mlp.drop.p > 0):
+            # drop_rate > 0 (cswin_unet.py:135,177-179 with live nn.Dropouts; no reference config uses it): the same kernels as
+            # separate autograd nodes, with cswin_dropout between the GEMM and the residual add
+            n1, n2 = self.norm1, self.norm2
+            qkv = ops.linear(ops.layer_norm(x, n1.weight, n1.bias, n1.eps), self.qkv.weight, self.qkv.bias)
+            att = ops.stripe_attention(qkv, self.patches_resolution, self.split_size, [m.idx for m in a], [m.num_heads for m in a],
+                                       [m.get_v.weight for m in a], [m.get_v.bias for m in a], a[0].scale)
+            x = ops.dropout(ops.linear(att, self.proj.weight, self.proj.bias), self.proj_drop.p, residual=x, row_scale=rs1)
+            return self.mlp(ops.layer_norm(x, n2.weight, n2.bias, n2.eps), residual=x, row_scale=rs2)
         return ops.cswin_block(x, self.patches_resolution, self.split_size, [m.idx for m in a], [m.num_heads for m in a],
                                a[0].scale, self.norm1, self.qkv, self.proj, self.norm2, self.mlp.fc1, self.mlp.fc2,
                                [m.get_v.weight for m in a], [m.get_v.bias for m in a], rs1, rs2)
@@ -302,7 +310,7 @@ class CSWinTransformer(nn.Module):
         self._predraw_drop_path(x.shape[0], x.device)
         x = self.stage1_conv_embed(x)
         if self.pos_drop.p > 0 and self.training:
-            raise NotImplementedError("pos_drop p > 0 is not implemented on the HIP path (reference config uses 0)")
+            x = ops.dropout(x, self.pos_drop.p)
         x = self._run(self.stage1, x)
         self.x1 = x
         x = self._run(self.stage2, self.merge1(x))

@@ -13,7 +13,7 @@ from torch.autograd.function import once_differentiable
 from ._lib import ReduceJob, WgradDesc, call, dev_f32, lib, ptr, stream
 
 __all__ = ["layer_norm", "linear", "linear_pair", "mlp", "stripe_attention", "cswin_block", "conv_tokens", "patch_embed_conv", "carafe_reassemble",
-           "tokens_to_nchw", "matmul_nn", "ce_dice_loss", "img2windows", "windows2img"]
+           "tokens_to_nchw", "matmul_nn", "ce_dice_loss", "dropout", "img2windows", "windows2img"]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -228,10 +228,12 @@ def linear_pair(x, w1, b1, w2, b2):
 
 
 class _Mlp(Function):
-    """fc1 -> GELU(erf) -> fc2 (cswin_unet.py:22-28) with the optional residual/DropPath epilogue of :179."""
+    """fc1 -> GELU(erf) -> drop -> fc2 -> drop (cswin_unet.py:22-28) with the optional residual/DropPath epilogue of :179.
+    drop_p = 0 (every reference config): two GEMMs with fused epilogues.  drop_p > 0: the two nn.Dropouts are separate
+    launches of cswin_dropout (masks regenerated from their seeds in backward; they commute with the GELU' factor)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, residual, row_scale):
+    def forward(ctx, x, w1, b1, w2, b2, residual, row_scale, drop_p, seeds):
         x, w1, b1, w2, b2 = (dev_f32(t) for t in (x, w1, b1, w2, b2))
         residual, row_scale = dev_f32(residual), dev_f32(row_scale)
         K = x.shape[-1]
@@ -242,10 +244,17 @@ class _Mlp(Function):
         call("cswin_linear_fwd", ptr(x), None, 0, ptr(w1), ptr(b1), ptr(pre), ptr(act), None, None, 1, M, Hd, K, stream())
         y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
         rps = _rows_per_sample(x) if row_scale is not None else 1
-        call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(b2), ptr(y), None, ptr(residual), ptr(row_scale), rps,
-             M, N, Hd, stream())
+        if drop_p > 0:
+            call("cswin_dropout", ptr(act), None, None, ptr(act), act.numel(), act.numel() // act.shape[0], drop_p, seeds[0], stream())
+            call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(b2), ptr(y), None, None, None, 1, M, N, Hd, stream())
+            call("cswin_dropout", ptr(y), ptr(residual), ptr(row_scale), ptr(y), y.numel(), y.numel() // y.shape[0], drop_p, seeds[1],
+                 stream())
+        else:
+            call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(b2), ptr(y), None, ptr(residual), ptr(row_scale), rps,
+                 M, N, Hd, stream())
         ctx.save_for_backward(x, w1, w2, pre, act, row_scale)
         ctx.has_res, ctx.rps, ctx.has_b1, ctx.has_b2 = residual is not None, rps, b1 is not None, b2 is not None
+        ctx.drop = (float(drop_p), seeds)
         return y
 
     @staticmethod
@@ -258,29 +267,41 @@ class _Mlp(Function):
         M = x.numel() // K
         dev = x.device
         st = stream()
+        drop_p, seeds = ctx.drop
+        dyl, rs_gemm = dy, row_scale                 # gradient of fc2's output, and the row factor still to be applied by the GEMMs
+        if drop_p > 0:
+            dyl = torch.empty_like(dy)
+            call("cswin_dropout", ptr(dy), None, ptr(row_scale), ptr(dyl), dy.numel(), dy.numel() // dy.shape[0], drop_p, seeds[1], st)
+            rs_gemm = None
         # d pre = (row_scale * dy @ w2) * gelu'(pre)   (GELU backward fused into the data-gradient epilogue)
         dpre = torch.empty_like(pre)
-        call("cswin_linear_bwd_data", ptr(dy), ptr(w2), ptr(dpre), None, 0, ptr(pre), ptr(row_scale), ctx.rps, None, M, N,
+        call("cswin_linear_bwd_data", ptr(dyl), ptr(w2), ptr(dpre), None, 0, ptr(pre), ptr(rs_gemm), ctx.rps, None, M, N,
              Hd, st)
+        if drop_p > 0:
+            call("cswin_dropout", ptr(dpre), None, None, ptr(dpre), dpre.numel(), dpre.numel() // dpre.shape[0], drop_p, seeds[0], st)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             call("cswin_linear_bwd_data", ptr(dpre), ptr(w1), ptr(dx), None, 0, None, None, 1, None, M, Hd, K, st)
-        with _side_stream(dy, act, dpre, x, row_scale):          # both weight gradients, off the data-gradient chain
+        with _side_stream(dyl, act, dpre, x, rs_gemm):          # both weight gradients, off the data-gradient chain
             dw2 = torch.empty_like(w2)
             db2 = torch.empty(N, dtype=torch.float32, device=dev) if ctx.has_b2 else None
             nbytes = max(lib().cswin_linear_bwd_weight_workspace(M, N, Hd), lib().cswin_linear_bwd_weight_workspace(M, Hd, K))
             ws = _ws(nbytes, dev)
-            call("cswin_linear_bwd_weight", ptr(dy), ptr(act), None, 0, ptr(row_scale), ctx.rps, ptr(dw2), ptr(db2), ptr(ws),
+            call("cswin_linear_bwd_weight", ptr(dyl), ptr(act), None, 0, ptr(rs_gemm), ctx.rps, ptr(dw2), ptr(db2), ptr(ws),
                  nbytes, M, N, Hd, None, stream())
             dw1 = torch.empty_like(w1)
             db1 = torch.empty(Hd, dtype=torch.float32, device=dev) if ctx.has_b1 else None
             call("cswin_linear_bwd_weight", ptr(dpre), ptr(x), None, 0, None, 1, ptr(dw1), ptr(db1), ptr(ws), nbytes, M, Hd, K, None, stream())
-        return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None
+        return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None, None, None
 
 
-def mlp(x, w1, b1, w2, b2, residual=None, row_scale=None):
-    return _Mlp.apply(x, w1, b1, w2, b2, residual, row_scale)
+def _draw_seeds(n):
+    return tuple(int(v) for v in torch.randint(0, 2 ** 62, (n,)).tolist())      # host RNG: torch.manual_seed controls it
+
+
+def mlp(x, w1, b1, w2, b2, residual=None, row_scale=None, drop_p=0.0):
+    return _Mlp.apply(x, w1, b1, w2, b2, residual, row_scale, float(drop_p), _draw_seeds(2) if drop_p > 0 else (0, 0))
 
 
 class _MatmulNN(Function):
@@ -686,8 +707,9 @@ def windows2img(img_splits_hw, H_sp, W_sp, H, W):
 # ------------------------------------------------------------------------------------------------
 class _CeDiceLoss(Function):
     @staticmethod
-    def forward(ctx, logits, labels, w_ce, w_dice, group):
+    def forward(ctx, logits, labels, w_ce, w_dice, group, probs, class_weight):
         logits = dev_f32(logits, "logits")
+        class_weight = dev_f32(class_weight)
         labels = labels.contiguous()
         if labels.dtype != torch.int64:
             labels = labels.long()
@@ -698,7 +720,7 @@ class _CeDiceLoss(Function):
         nbytes = lib().cswin_loss_workspace(B, ncls, HW)
         ws = _ws(nbytes, dev)
         sums = torch.empty(1 + 3 * ncls, dtype=torch.float32, device=dev)
-        call("cswin_loss_sums", ptr(logits), ptr(labels), ptr(sums), ptr(ws), nbytes, B, ncls, HW, st)
+        call("cswin_loss_sums", ptr(logits), ptr(labels), ptr(sums), ptr(ws), nbytes, B, ncls, HW, int(probs), st)
         world = 1
         if group is not None:
             import torch.distributed as dist
@@ -707,10 +729,11 @@ class _CeDiceLoss(Function):
                 dist.all_reduce(sums, group=group)      # 1 + 3*ncls floats: the reference's global-batch Dice
         out = torch.empty(3, dtype=torch.float32, device=dev)
         coef = torch.empty(2 * ncls, dtype=torch.float32, device=dev)
-        call("cswin_loss_finalize", ptr(sums), ptr(out), ptr(coef), float(B * HW * world), ncls, w_ce, w_dice, stream())
+        call("cswin_loss_finalize", ptr(sums), ptr(out), ptr(coef), float(B * HW * world), ncls, w_ce, w_dice, ptr(class_weight),
+             stream())
         ctx.save_for_backward(logits, labels, coef)
         # gradients are averaged over ranks afterwards: local CE mean -> ce/(B*HW); global Dice -> * world
-        ctx.meta = (w_ce / float(B * HW), w_dice / ncls * world)
+        ctx.meta = (w_ce / float(B * HW), w_dice / ncls * world, int(probs))
         loss = out[0].clone()
         ctx.mark_non_differentiable(out)
         return loss, out
@@ -719,17 +742,53 @@ class _CeDiceLoss(Function):
     @once_differentiable
     def backward(ctx, gloss, _gout):
         logits, labels, coef = ctx.saved_tensors
-        ce_scale, dice_scale = ctx.meta
+        ce_scale, dice_scale, probs = ctx.meta
         B, ncls = logits.shape[:2]
         HW = logits.numel() // (B * ncls)
         gloss = dev_f32(gloss.reshape(1))
         dlogits = torch.empty_like(logits)
         call("cswin_loss_bwd", ptr(logits), ptr(labels), ptr(coef), ptr(gloss), ptr(dlogits), ce_scale, dice_scale, B, ncls,
-             HW, stream())
-        return dlogits, None, None, None, None
+             HW, probs, stream())
+        return dlogits, None, None, None, None, None, None
 
 
-def ce_dice_loss(logits, labels, w_ce=0.4, w_dice=0.6, group=None):
+def ce_dice_loss(logits, labels, w_ce=0.4, w_dice=0.6, group=None, inputs_are_probs=False, class_weight=None):
     """0.4*CE + 0.6*Dice (trainer.py:55-57).  Returns (loss, stats) with stats = [loss, ce, dice] (no host sync).
-    With a process group the 1+3*ncls Dice/CE sums are all-reduced so Dice is the global-batch Dice."""
-    return _CeDiceLoss.apply(logits, labels, float(w_ce), float(w_dice), group)
+    With a process group the 1+3*ncls Dice/CE sums are all-reduced so Dice is the global-batch Dice.
+    inputs_are_probs: the input holds probabilities (DiceLoss(softmax=False)); class_weight: (ncls,) device tensor or None."""
+    if inputs_are_probs and w_ce != 0.0:
+        raise ValueError("ce_dice_loss: cross entropy needs logits; with inputs_are_probs pass w_ce=0")
+    return _CeDiceLoss.apply(logits, labels, float(w_ce), float(w_dice), group, bool(inputs_are_probs), class_weight)
+
+
+# ------------------------------------------------------------------------------------------------
+# dropout (+ residual add and DropPath factor)
+# ------------------------------------------------------------------------------------------------
+class _Dropout(Function):
+    @staticmethod
+    def forward(ctx, x, residual, row_scale, p, seed):
+        x, residual, row_scale = dev_f32(x, "dropout input"), dev_f32(residual), dev_f32(row_scale)
+        y = torch.empty_like(x)
+        eps = x.numel() // x.shape[0]
+        call("cswin_dropout", ptr(x), ptr(residual), ptr(row_scale), ptr(y), x.numel(), eps, float(p), int(seed), stream())
+        ctx.save_for_backward(row_scale)
+        ctx.meta = (float(p), int(seed), eps, residual is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (row_scale,) = ctx.saved_tensors
+        p, seed, eps, has_res = ctx.meta
+        dy = dev_f32(dy)
+        dx = torch.empty_like(dy)
+        call("cswin_dropout", ptr(dy), None, ptr(row_scale), ptr(dx), dy.numel(), eps, p, seed, stream())
+        return dx, (dy if has_res else None), None, None, None
+
+
+def dropout(x, p, residual=None, row_scale=None, seed=None):
+    """residual + row_scale[sample] * dropout_p(x)  (nn.Dropout followed by the block's residual add, cswin_unet.py:27,135,178-179).
+    The keep mask is a counter-based hash of (seed, element index); backward regenerates it."""
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())        # host RNG (torch.manual_seed controls it); not capturable
+    return _Dropout.apply(x, residual, row_scale, p, seed)

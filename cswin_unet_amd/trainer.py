@@ -114,7 +114,7 @@ class HipEngine:
         hw = logits.numel() // (B * ncls)
         nbytes = lib().cswin_loss_workspace(B, ncls, hw)
         ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=logits.device)
-        call("cswin_loss_sums", ptr(logits.detach()), ptr(lab), ptr(self.sums), ptr(ws), nbytes, B, ncls, hw, stream())
+        call("cswin_loss_sums", ptr(logits.detach()), ptr(lab), ptr(self.sums), ptr(ws), nbytes, B, ncls, hw, 0, stream())
         return logits
 
     def _loss_grad(self, logits, lab, dice_grad_scale):
@@ -122,7 +122,7 @@ class HipEngine:
         hw = logits.numel() // (B * ncls)
         dlogits = torch.empty_like(logits)
         call("cswin_loss_bwd", ptr(logits.detach()), ptr(lab), ptr(self._coef), None, ptr(dlogits),
-             self.w_ce / float(B * hw), self.w_dice / ncls * dice_grad_scale, B, ncls, hw, stream())
+             self.w_ce / float(B * hw), self.w_dice / ncls * dice_grad_scale, B, ncls, hw, 0, stream())
         return dlogits
 
     def _backward_decoder(self, logits, lab, dice_grad_scale):
@@ -237,7 +237,7 @@ class HipEngine:
     def finalize(self, n_pixels_global):
         """sums (already all-reduced) -> stats [loss, ce, dice] and the Dice gradient coefficients."""
         call("cswin_loss_finalize", ptr(self.sums), ptr(self.stats), ptr(self._coef), float(n_pixels_global), self.ncls,
-             self.w_ce, self.w_dice, stream())
+             self.w_ce, self.w_dice, None, stream())
 
     def backward_phases(self, dice_grad_scale):
         """Generator: runs one backward phase per iteration and yields the [lo, hi) range of flat_grad it completed."""

@@ -25,15 +25,17 @@ class DiceLoss(nn.Module):
         self.n_classes = n_classes
 
     def forward(self, inputs, target, weight=None, softmax=False):
-        """Mean over classes of 1 - (2 sum(p t) + s) / (sum(p p) + sum(t t) + s), sums over the whole batch (utils.py:22-45).
-        The fused kernel takes logits: ``softmax=True`` (how trainer.py:56 calls it) and uniform class weights."""
-        if not softmax:
-            raise NotImplementedError("DiceLoss on the HIP path takes logits: call it with softmax=True (trainer.py:56)")
-        if weight is not None and any(float(w) != 1.0 for w in weight):
-            raise NotImplementedError("DiceLoss: per-class weights other than 1 are not implemented on the HIP path")
+        """sum_c weight[c] * (1 - (2 sum(p t) + s) / (sum(p p) + sum(t t) + s)) / n_classes, sums over the whole batch
+        (utils.py:22-45).  ``softmax=True`` (how trainer.py:56 calls it): inputs are logits, the softmax is fused;
+        ``softmax=False``: inputs are taken as probabilities as they are.  ``weight``: per-class factors (default all 1)."""
         if inputs.shape[1] != self.n_classes:
             raise AssertionError('predict {} & target shape do not match ({} classes)'.format(tuple(inputs.shape), self.n_classes))
-        loss, _ = ops.ce_dice_loss(inputs, target, w_ce=0.0, w_dice=1.0)
+        cw = None
+        if weight is not None:
+            if len(weight) != self.n_classes:
+                raise AssertionError('weight has {} entries for {} classes'.format(len(weight), self.n_classes))
+            cw = torch.as_tensor([float(w) for w in weight], dtype=torch.float32, device=inputs.device)
+        loss, _ = ops.ce_dice_loss(inputs, target, w_ce=0.0, w_dice=1.0, inputs_are_probs=not softmax, class_weight=cw)
         return loss
 
 

@@ -165,18 +165,34 @@ int cswin_carafe_bwd(const float* dout, const float* z, const float* wt_save, fl
  * logits (B, ncls, HW) fp32, labels (B, HW) int64.  sums[1 + 3*ncls] = {sum -log p[label], intersect_c, y_sum_c,
  * z_sum_c}: all-reduce these across data-parallel ranks for the reference's global-batch Dice. */
 size_t cswin_loss_workspace(int B, int ncls, long HW);
+/* inputs_are_probs != 0: `logits` already holds class probabilities (DiceLoss(..., softmax=False), utils.py:32-34): no softmax
+ * is applied, the gradient is d/d(probabilities) and only the Dice term is meaningful (call with w_ce = 0).
+ * class_weight: ncls device floats or NULL (= all 1): utils.py:44 `loss += dice * weight[i]`.
+ * A label outside [0, ncls) makes sums[0] (hence the loss) NaN: the device-side counterpart of CrossEntropyLoss raising. */
 int cswin_loss_sums(const float* logits, const long long* labels, float* sums, void* workspace, size_t ws_bytes, int B,
-                    int ncls, long HW, void* stream);
+                    int ncls, long HW, int inputs_are_probs, void* stream);
 int cswin_loss_finalize(const float* sums, float* out3, float* coef, double n_pixels, int ncls, float w_ce,
-                        float w_dice, void* stream);
+                        float w_dice, const float* class_weight, void* stream);
 int cswin_loss_bwd(const float* logits, const long long* labels, const float* coef, const float* grad_out,
-                   float* dlogits, float ce_scale, float dice_scale, int B, int ncls, long HW, void* stream);
+                   float* dlogits, float ce_scale, float dice_scale, int B, int ncls, long HW, int inputs_are_probs,
+                   void* stream);
 
 /* ---- optimiser: torch.optim.SGD(momentum, weight_decay) (trainer.py:42,60) on one flat buffer ---- */
 int cswin_sgd_flat(float* p, const float* g, float* m, long n, const float* lr_dev, float momentum,
                    float weight_decay, float grad_scale, void* stream);
 /* table: device array of {const float* src; float* dst; long long n;} (24-byte records), one workgroup each */
 int cswin_multi_copy(const void* table, int nchunks, void* stream);
+
+/* ---- nn.Dropout(p) of the reference (cswin_unet.py:20,25,27 Mlp.drop; :135 proj_drop; :346 pos_drop), fused with the residual
+ * add + DropPath row factor that follows it where there is one (:178-179):
+ *   keep(i) = counter-based hash of (seed, i) >= p   (no mask tensor: backward regenerates it from the same seed)
+ *   forward : y[i]  = (residual ? residual[i] : 0) + row_scale[i / (rows_per_sample * C)] * keep(i) / (1 - p) * x[i]
+ *   backward: dx[i] =                               row_scale[...]                          * keep(i) / (1 - p) * dy[i]
+ * x / y / dy / dx: n floats, 16-B aligned; row_scale: per-sample floats or NULL; elems_per_sample = L * C.  In place (y == x) is
+ * allowed.  The random stream is this library's own: torch's Philox stream cannot be reproduced (parity unpinned, as for
+ * DropPath); tests extract the mask by running the kernel on ones. */
+int cswin_dropout(const float* x, const float* residual, const float* row_scale, float* y, long n, long elems_per_sample,
+                  float p, unsigned long long seed, void* stream);
 /* bf16 gradient wire for the data-parallel all-reduce (replaces DataParallel's fp32 reduce_add, trainer.py:37-38):
    fp32 -> bf16 round-to-nearest-even / bf16 -> fp32 over n elements (src of pack, dst of unpack 16-B aligned) */
 int cswin_pack_bf16(const float* src, void* dst_bf16, long n, void* stream);

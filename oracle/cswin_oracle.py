@@ -114,9 +114,11 @@ def block_is_single_branch(reso, split, last_stage):
     return bool(last_stage or reso == split)            # cswin_unet.py:128-133
 
 
-def cswin_block(x, P, pre, dim, reso, heads, split, last_stage=False, keep_scale=None):
+def cswin_block(x, P, pre, dim, reso, heads, split, last_stage=False, keep_scale=None, drop_factors=None):
     """keep_scale: optional (B,) tensor = DropPath mask/keep_prob applied to both residual
-    branches' updates (timm DropPath semantics); None = identity (eval / p=0)."""
+    branches' updates (timm DropPath semantics); None = identity (eval / p=0).
+    drop_factors: optional (f_proj, f_act, f_fc2) elementwise mask/(1-p) tensors standing for the three live nn.Dropouts of a
+    block with drop > 0: proj_drop (cswin_unet.py:135,177), Mlp.drop after GELU (:25) and after fc2 (:27)."""
     B, L, C = x.shape
     assert L == reso * reso, "flatten img_tokens has wrong size"
     dp = (lambda t: t) if keep_scale is None else (lambda t: t * keep_scale.view(-1, 1, 1))
@@ -135,11 +137,12 @@ def cswin_block(x, P, pre, dim, reso, heads, split, last_stage=False, keep_scale
                                         P[pre + f"attns.{br}.get_v.weight"], P[pre + f"attns.{br}.get_v.bias"],
                                         reso, br, split, heads // 2))
         att = torch.cat(parts, dim=2)
-    x = x + dp(F.linear(att, P[pre + "proj.weight"], P[pre + "proj.bias"]))
+    f_proj, f_act, f_fc2 = drop_factors if drop_factors is not None else (1.0, 1.0, 1.0)
+    x = x + dp(F.linear(att, P[pre + "proj.weight"], P[pre + "proj.bias"]) * f_proj)
     h = F.layer_norm(x, (C,), P[pre + "norm2.weight"], P[pre + "norm2.bias"], 1e-5)
     h = F.linear(h, P[pre + "mlp.fc1.weight"], P[pre + "mlp.fc1.bias"])
-    h = F.gelu(h)                                                          # exact erf GELU (nn.GELU default)
-    h = F.linear(h, P[pre + "mlp.fc2.weight"], P[pre + "mlp.fc2.bias"])
+    h = F.gelu(h) * f_act                                                  # exact erf GELU (nn.GELU default)
+    h = F.linear(h, P[pre + "mlp.fc2.weight"], P[pre + "mlp.fc2.bias"]) * f_fc2
     return x + dp(h)
 
 

@@ -41,6 +41,8 @@ def test_library_loads_and_exports_header_symbols():
                 assert t is ctypes.c_double, (name, a)
             elif a.startswith("size_t"):
                 assert t is ctypes.c_size_t, (name, a)
+            elif a.startswith("unsigned long long"):
+                assert t is ctypes.c_ulonglong, (name, a)
             elif a.startswith("long"):
                 assert t is ctypes.c_long, (name, a)
             else:

@@ -841,3 +841,95 @@ def test_bf16_wire_pack_unpack():
         back = torch.empty(n, dtype=torch.float32, device=DEV)
         call("cswin_unpack_bf16", ptr(wire), ptr(back), n, stream())
         assert torch.equal(back, wire.float())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# boundary holes closed in round 2: nn.Dropout sites (drop_rate > 0), DiceLoss(softmax=False, weight=...)
+# ------------------------------------------------------------------------------------------------------------------
+def _dropout_factor(shape, p, seed):
+    """The mask / (1 - p) tensor cswin_dropout applies for this seed (extracted by running the kernel on ones)."""
+    from cswin_unet_amd._lib import call, ptr, stream
+    ones = torch.ones(shape, device=DEV)
+    out = torch.empty_like(ones)
+    call("cswin_dropout", ptr(ones), None, None, ptr(out), ones.numel(), ones.numel() // shape[0], float(p), int(seed), stream())
+    return out
+
+
+def test_dropout_kernel_statistics_and_backward(ops):
+    p, seed = 0.3, 123456789
+    x = T(det_normal("drop.x", (4, 196, 256)), grad=True)
+    res = T(det_normal("drop.res", (4, 196, 256)), grad=True)
+    rs = torch.tensor([1.0, 0.0, 2.5, 1.25], device=DEV)
+    f = _dropout_factor((4, 196, 256), p, seed)
+    keep = (f > 0).float().mean().item()
+    assert abs(keep - (1 - p)) < 5e-3 and set(torch.unique(f).tolist()) == {0.0, float(np.float32(1.0) / np.float32(1 - p))}
+    assert not torch.equal(f, _dropout_factor((4, 196, 256), p, seed + 1))          # another seed, another mask
+    y = ops.dropout(x, p, residual=res, row_scale=rs, seed=seed)
+    ref = res + rs[:, None, None] * f * x
+    assert torch.allclose(y, ref, rtol=1e-6, atol=1e-6)
+    dy = T(det_normal("drop.dy", (4, 196, 256)))
+    y.backward(dy)
+    assert torch.allclose(x.grad, rs[:, None, None] * f * dy, rtol=1e-6, atol=1e-6) and torch.equal(res.grad, dy)
+
+
+def test_block_with_drop_rate_matches_composition(N, ops):
+    """CSWinBlock with drop_rate > 0 (live proj_drop and Mlp.drop, cswin_unet.py:25,27,135) against the same block computed by
+    the oracle with the masks the kernels drew (parity of the random stream itself is unpinned, as for DropPath)."""
+    dim, reso, heads, split, p = 128, 28, 4, 2, 0.25
+    blk = N.CSWinBlock(dim, reso, heads, split, qkv_bias=True, drop=p).to(DEV)
+    fill_state_dict(blk).train()
+    x = T(det_normal("dropblk.x", (2, reso * reso, dim)), grad=True)
+    # seeds: 11 proj_drop, 22 Mlp.drop after GELU, 33 Mlp.drop after fc2
+    import cswin_unet_amd.ops as O_
+    real_dropout, real_draw = O_.dropout, O_._draw_seeds
+    O_.dropout = lambda x_, p_, residual=None, row_scale=None, seed=None: real_dropout(x_, p_, residual, row_scale, 11)
+    O_._draw_seeds = lambda n: (22, 33)
+    try:
+        y = blk(x)
+        dy = T(det_normal("dropblk.dy", tuple(y.shape)))
+        y.backward(dy)
+    finally:
+        O_.dropout, O_._draw_seeds = real_dropout, real_draw
+    f1 = _dropout_factor((2, reso * reso, dim), p, 11).cpu()
+    f2 = _dropout_factor((2, reso * reso, 4 * dim), p, 22).cpu()
+    f3 = _dropout_factor((2, reso * reso, dim), p, 33).cpu()
+    P = {k: v.detach().cpu().clone().requires_grad_() for k, v in blk.state_dict().items()}
+    xr = x.detach().cpu().clone().requires_grad_()
+    yr = O.cswin_block(xr, P, "", dim, reso, heads, split, drop_factors=(f1, f2, f3))
+    yr.backward(dy.cpu())
+    rel_err(y, yr, "dropblk.y")
+    rel_err(x.grad, xr.grad, "dropblk.dx")
+    for n in ("qkv.weight", "proj.weight", "mlp.fc1.weight", "mlp.fc2.bias", "norm2.weight"):
+        rel_err(dict(blk.named_parameters())[n].grad, P[n].grad, "dropblk.grad." + n)
+
+
+def test_dice_loss_probabilities_and_class_weights():
+    """utils.DiceLoss(n)(probs, target, weight=w, softmax=False) (utils.py:32-45) vs a direct restatement."""
+    from cswin_unet_amd.utils import DiceLoss
+    ncls = 4
+    logits = det_normal("dicew.logits", (2, ncls, 24, 24))
+    lab = det_labels("dicew.lab", (2, 24, 24), ncls)
+    w = [0.5, 1.0, 2.0, 0.25]
+
+    def restated(pr, target):
+        loss = 0.0
+        for c in range(ncls):
+            t = (target == c).float()
+            loss = loss + w[c] * (1 - (2 * (pr[:, c] * t).sum() + 1e-5) / ((pr[:, c] ** 2).sum() + (t * t).sum() + 1e-5))
+        return loss / ncls
+    probs = T(torch.softmax(torch.from_numpy(logits), 1).numpy(), grad=True)
+    loss = DiceLoss(ncls)(probs, T(lab), weight=w, softmax=False)
+    loss.backward()
+    pr = torch.softmax(torch.from_numpy(logits), 1).requires_grad_()
+    ref = restated(pr, torch.from_numpy(lab))
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5
+    rel_err(probs.grad, pr.grad, "dicew.dprobs")
+    lg = T(logits, grad=True)                                   # softmax=True with weights
+    loss2 = DiceLoss(ncls)(lg, T(lab), weight=w, softmax=True)
+    loss2.backward()
+    lr_ = torch.from_numpy(logits).requires_grad_()
+    ref2 = restated(torch.softmax(lr_, 1), torch.from_numpy(lab))
+    ref2.backward()
+    assert abs(float(loss2) - float(ref2)) < 1e-5
+    rel_err(lg.grad, lr_.grad, "dicew.dlogits")
