@@ -1070,7 +1070,9 @@ int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* co
         case 5: case 6: rc = launch_fwd<6>(p, nwg, st); break;
         case 7: rc = launch_fwd<7>(p, nwg, st); break;
         case 8: case 9: rc = launch_fwd<9>(p, nwg, st); break;
-        case 18: rc = launch_fwd<18>(p, nwg, st); break;
+        case 10: case 11: case 12: rc = launch_fwd<12>(p, nwg, st); break;
+        case 13: case 14: case 15: rc = launch_fwd<15>(p, nwg, st); break;
+        case 16: case 17: case 18: rc = launch_fwd<18>(p, nwg, st); break;
         default:
             cswin_set_error("attn_fwd: window of %d tokens unsupported", p.br[0].H_sp * p.br[0].W_sp);
             return CSWIN_ERR_UNSUPPORTED;

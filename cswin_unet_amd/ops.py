@@ -24,7 +24,14 @@ __all__ = ["layer_norm", "linear", "linear_pair", "mlp", "stripe_attention", "cs
 # stays a plain single-stream program), weight-gradient launches go to a second HIP stream forked from the current
 # one, so the two chains fill each other's launch ramps and tails (every kernel of this model is 10-50 us).  The fork /
 # join edges are ordinary events, so the same code is captured into hipGraphs as parallel branches.
-_overlap = {"on": False, "stream": None, "pending": []}
+_overlap = {"on": False, "stream": None, "pending": [], "block": False}
+
+
+def set_block_overlap(enabled: bool):
+    """CSWinBlock backward: launch the three weight gradients that are ready before the attention backward (fc2, fc1, proj)
+    on the side stream, so that they run beside the attention kernel (384 seven-wave workgroups at B = 24: half of the
+    CUs hold one, with LDS and wave slots to spare) instead of after it."""
+    _overlap["block"] = bool(enabled)
 
 
 def set_wgrad_overlap(enabled: bool):
@@ -477,6 +484,16 @@ class _CSWinBlock(Function):
         call("cswin_linear_bwd_data", ptr(dx1), ptr(wp), ptr(datt), None, 0, None, ptr(rs1), L, None, M, C, C, st)
         dwp, dbp = torch.empty_like(wp), E(C)
         defer_wgrad(2, dx1, att, rs1, dwp, dbp, 3, C, C)
+        early = None
+        if _overlap["block"]:
+            # fc2, fc1 and proj weight gradients have all their operands now: they run BESIDE the attention backward
+            early = (ReduceJob * 3)()
+            if _overlap["stream"] is None:
+                _overlap["stream"] = torch.cuda.Stream()
+            side = _overlap["stream"]
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 3, ctypes.cast(early, ctypes.c_void_p), stream())
         dqkv = torch.empty_like(qkv)
         dlw = [torch.empty_like(t) for t in lw]
         dlb = [E(t.shape[0]) for t in lw]
@@ -489,7 +506,13 @@ class _CSWinBlock(Function):
         dbqkv = E(3 * C) if has_qkv_bias else None
         defer_wgrad(3, dqkv, h1, None, dwqkv, dbqkv, 4, 3 * C, C)
         wjobs = (ReduceJob * 4)()
-        call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(wjobs, ctypes.c_void_p), st)
+        if early is not None:
+            call("cswin_linear_bwd_weight_batch", ctypes.cast(ctypes.byref(wg[3]), ctypes.c_void_p), 1,
+                 ctypes.cast(ctypes.byref(wjobs[3]), ctypes.c_void_p), st)
+            for slot in range(3):
+                wjobs[slot] = early[slot]
+        else:
+            call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(wjobs, ctypes.c_void_p), st)
         for slot, ji in enumerate((0, 1, 3, 4)):
             jobs[ji] = wjobs[slot]
         dh1 = datt                                                     # reuse again
@@ -497,6 +520,8 @@ class _CSWinBlock(Function):
         dx, dg1, dbt1 = torch.empty_like(x), E(C), E(C)
         call("cswin_layernorm_bwd", ptr(dh1), ptr(x), ptr(m1), ptr(r1), ptr(g1), ptr(dx1), ptr(dx), ptr(dg1), ptr(dbt1), wsp[5],
              sizes[5], M, C, J(5), st)
+        if early is not None:
+            torch.cuda.current_stream().wait_stream(_overlap["stream"])      # slabs of the early weight gradients are complete
         call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), 6 + nb, st)
         grads = (dx, None, None, None, None, None, None, None, None, None, dg1, dbt1, dwqkv, dbqkv, dwp, dbp, dg2, dbt2, dw1, db1,
                  dw2, db2)

@@ -94,6 +94,7 @@ class HipEngine:
         self._wire = {}
         from . import ops
         ops.set_wgrad_overlap(os.environ.get("CSWIN_WGRAD_OVERLAP", "0") != "0")
+        ops.set_block_overlap(os.environ.get("CSWIN_BLOCK_OVERLAP", "0") != "0")
 
     # flat views the protocol all-reduces / broadcasts
     @property
