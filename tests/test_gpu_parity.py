@@ -230,7 +230,7 @@ def test_attention_384_fwd_bwd_vs_golden(N, golden, reso, idx, split, dim, heads
             f.write(f"attn384_golden.{key}.{name}: {err:.3e}\n")
 
 
-@pytest.mark.parametrize("reso,idx,split,dim,heads", [(20, 0, 8, 64, 2), (24, 1, 8, 64, 2), (16, -1, 16, 128, 4), (20, 1, 10, 64, 2),
+@pytest.mark.parametrize("reso,idx,split,dim,heads", [(24, 1, 8, 64, 2), (16, -1, 16, 128, 4), (20, 1, 10, 64, 2), (24, 0, 6, 48, 2),
                                                       (56, 0, 1, 48, 2), (28, 1, 2, 96, 4), (14, 0, 7, 192, 8),
                                                         (7, -1, 7, 384, 16), (24, 1, 12, 192, 8), (28, 0, 2, 32, 2),
                                                         (14, 1, 7, 32, 4)])
