@@ -25,6 +25,8 @@
 
 // wsgemm.hip: weight-stationary family for plain tall-skinny Linears (returns 1 when the shape is not served there)
 int cswin_ws_gemm(int mode, int epi_mode, const float* A, const float* W, const void* epilogue, int M, int N, int R, void* stream);
+// wgrad16.hip: bf16-operand weight gradients with transposing LDS reads (bf16 matmul mode)
+int cswin_wgrad16_batch(const cswin_wgrad_desc* d, int n, const int* splits, const int* rows_per_split, void* stream);
 
 namespace {
 
@@ -761,6 +763,28 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
                                              d[i].workspace, d[i].ws_bytes, d[i].M, d[i].N, d[i].K, &deferred[i], stream);
             if (rc) return rc;
         }
+        return CSWIN_OK;
+    }
+    static const int w16_off = getenv("CSWIN_WGRAD16") ? atoi(getenv("CSWIN_WGRAD16")) == 0 : 0;     // tuning aid
+    if (g_matmul_precision == 1 && !w16_off) {
+        // bf16 operands: 128 x 128 tiles, ~3 workgroups per CU over the whole batch (load-bound: see wgrad16.hip)
+        int splits[WGRAD_BATCH], rps[WGRAD_BATCH];
+        for (int i = 0; i < n; ++i) {
+            const int M = d[i].M, N = d[i].N, K = d[i].K;
+            const long slab = ((long)N * K + N) * (long)sizeof(float);
+            const int tiles = cdiv(N, 128) * cdiv(K, 128);
+            int s = (768 / n) / tiles;
+            const int cap = (int)(d[i].ws_bytes / slab);
+            if (s > cap) s = cap;
+            if (s > M / 64) s = M / 64;
+            if (s < 1) s = 1;
+            rps[i] = cdiv(cdiv(M, s), 32) * 32;
+            splits[i] = cdiv(M, rps[i]);
+            const long nk = (long)N * K;
+            deferred[i] = cswin_reduce_job{(const float*)d[i].workspace, d[i].dw, d[i].dbias, nk, nk + (d[i].dbias ? N : 0), nk + N, splits[i], 0};
+        }
+        cswin_wgrad16_batch(d, n, splits, rps, stream);
+        CSWIN_LAUNCH_CHECK();
         return CSWIN_OK;
     }
     WgradBatch b = {};

@@ -932,3 +932,45 @@ def test_dice_loss_probabilities_and_class_weights():
     ref2.backward()
     assert abs(float(loss2) - float(ref2)) < 1e-5
     rel_err(lg.grad, lr_.grad, "dicew.dlogits")
+
+
+@pytest.mark.parametrize("shapes", [[(4704, 256, 1024), (4704, 1024, 256), (4704, 256, 256), (4704, 768, 256)],
+                                    [(75264, 64, 256), (75264, 192, 64)], [(1176, 512, 2048)], [(777, 132, 100), (3000, 64, 64)]])
+def test_linear_weight_gradient_batch_bf16(bf16_matmul, shapes):
+    """bf16 matmul mode of cswin_linear_bwd_weight_batch (csrc/wgrad16.hip: transposing LDS reads + bf16 MFMA, fp32 accumulate).
+    Two bounds: (a) against the same product of the bf16-ROUNDED operands in fp32 -- what the kernel is specified to compute --
+    1e-4 of RMS (only the summation order differs); (b) against the exact fp32 product: operand rounding is 2^-9 relative
+    per factor, random in sign, so the result is within ~2^-8 of its RMS: bound 1e-2."""
+    import ctypes
+    from cswin_unet_amd._lib import ReduceJob, WgradDesc, call, lib, stream
+    n = len(shapes)
+    wg, jobs, keep, refs = (WgradDesc * n)(), (ReduceJob * n)(), [], []
+    for i, (M, N_, K) in enumerate(shapes):
+        dy, x = det_normal(f"wb16.dy{i}", (M, N_)), det_normal(f"wb16.x{i}", (M, K))
+        rps = (M + 2) // 3
+        rs = np.array([0.0, 1.25, 0.5], np.float32) if i % 2 == 0 else None
+        with_bias = i != 1
+        dyd, xd = T(dy), T(x)
+        rsd = T(rs) if rs is not None else None
+        dw = torch.empty(N_, K, device=DEV)
+        db = torch.empty(N_, device=DEV) if with_bias else None
+        nbytes = lib().cswin_linear_bwd_weight_workspace(M, N_, K)
+        ws = torch.empty(nbytes // 4 + 4, device=DEV)
+        keep += [dyd, xd, rsd, ws]
+        wg[i].dy, wg[i].x, wg[i].row_scale = dyd.data_ptr(), xd.data_ptr(), (rsd.data_ptr() if rsd is not None else None)
+        wg[i].dw, wg[i].dbias, wg[i].workspace, wg[i].ws_bytes = dw.data_ptr(), (db.data_ptr() if with_bias else None), ws.data_ptr(), nbytes
+        wg[i].rows_per_sample, wg[i].M, wg[i].N, wg[i].K = rps, M, N_, K
+        scale = np.ones((M, 1), np.float32) if rs is None else np.array([rs[m // rps] for m in range(M)], np.float32)[:, None]
+        dys = torch.from_numpy(dy * scale)
+        xt = torch.from_numpy(x)
+        r16 = lambda t: t.to(torch.bfloat16).to(torch.float64)
+        refs.append((dw, db, (r16(dys).T @ r16(xt)).float(), (dys.double().T @ xt.double()).float(), dys.double().sum(0).float()))
+    call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), n, ctypes.cast(jobs, ctypes.c_void_p), stream())
+    call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), n, stream())
+    for i, (dw, db, ref16, ref32, db_ref) in enumerate(refs):
+        got = dw.cpu()
+        rms = float(ref32.pow(2).mean().sqrt())
+        e16, e32 = float((got - ref16).abs().max()) / rms, float((got - ref32).abs().max()) / rms
+        assert e16 < 1e-4 and e32 < 1e-2, (i, shapes[i], e16, e32)
+        if db is not None:                                   # the bias gradient is summed in fp32 from the fp32 dy
+            assert float((db.cpu() - db_ref).abs().max()) / float(db_ref.pow(2).mean().sqrt() + 1e-30) < 1e-4, i
