@@ -49,10 +49,28 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// exact (erf) GELU, matching torch.nn.GELU() default, and its derivative
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-based GELU (torch.nn.GELU() default, cswin_unet.py:24) and its derivative.  erf by Abramowitz & Stegun 7.1.26:
+//   erf(u) = 1 - (a1 t + a2 t^2 + a3 t^3 + a4 t^4 + a5 t^5) exp(-u^2),  t = 1 / (1 + p u),  u >= 0,  |error| <= 1.5e-7
+// i.e. at the rounding level of fp32 for (1 + erf): one v_exp, one v_rcp and seven FMAs instead of libm's erff, and the
+// derivative reuses the same exponential (exp(-u^2) = exp(-x^2 / 2) with u = x / sqrt(2)).  The GEMM epilogues that apply
+// these are VALU-bound once the MFMAs are bf16 (fc1 forward 21.8 vs 12.2 us, fc2 data gradient 27.8 vs 16.7 us with erff).
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
+    const float u = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+    e = __expf(-u * u);
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float erf_abs = fmaf(-poly, e, 1.0f);
+    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    return fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
 // ---- partial-slab reductions ------------------------------------------------------------------------------------

@@ -315,9 +315,14 @@ __device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Ep
                 if (B_RC) {
                     *reinterpret_cast<bf16x4*>(&Bs16[(b_r + q * B_RPP) * LD16 + 4 * b_c]) = __builtin_convertvector(pb[q], bf16x4);
                 } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        Bs16[(4 * b_c + e) * LD16 + b_r + q * B_RPP] = __builtin_bit_cast(unsigned short, (__bf16)pb[q][e]);
+                    // source rows run along the REDUCTION index (data gradient: W[r][k]): keep them as they arrive, [r][BN] bf16
+                    // rows of 128 B, and let ds_read_b64_tr_b16 do the transpose when the fragments are read (below).  16-B
+                    // chunks are XOR-swizzled with bit 1 of the row so that the 4-row x 16-column transposed reads of a
+                    // 32-lane half fall into 64 distinct banks.
+                    static_assert(B_RC || BN == 64, "transposed-read B image is laid out for 64-column tiles");
+                    const int row = b_r + q * B_RPP;
+                    *reinterpret_cast<bf16x4*>(&Bs16[row * BN + 8 * ((b_c >> 1) ^ (((row >> 1) & 1) << 2)) + 4 * (b_c & 1)]) =
+                        __builtin_convertvector(pb[q], bf16x4);
                 }
             } else {
                 *reinterpret_cast<f32x4*>(&Bs[(b_r + q * B_RPP) * LDB + 4 * b_c]) = pb[q];
@@ -363,8 +368,25 @@ __device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Ep
                     for (int i = 0; i < FM; ++i)
                         af[i] = *reinterpret_cast<const bf16x8*>(&As16[(wm0 + i * 32 + li) * LD16 + kk + 8 * lh]);
 #pragma unroll
-                    for (int j = 0; j < FN; ++j)
-                        bf[j] = *reinterpret_cast<const bf16x8*>(&Bs16[(wn0 + j * 32 + li) * LD16 + kk + 8 * lh]);
+                    for (int j = 0; j < FN; ++j) {
+                        if constexpr (B_RC) {
+                            bf[j] = *reinterpret_cast<const bf16x8*>(&Bs16[(wn0 + j * 32 + li) * LD16 + kk + 8 * lh]);
+                        } else {
+                            // lane (q, p) of its 16-lane group supplies row r0 + q, columns c0 + 4 p .. + 3; it receives column
+                            // c0 + (lane & 15) of rows r0 .. r0 + 3: two reads give the 8 reduction values of this lane's column
+                            typedef short s16x4 __attribute__((ext_vector_type(4)));
+                            typedef short s16x8 __attribute__((ext_vector_type(8)));
+                            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                            const int col = wn0 + j * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+                            const int row = kk + 8 * lh + ((lane & 15) >> 2);
+                            const int sw = ((row >> 1) & 1) << 2;               // rows row and row + 4 share bit 1
+                            const unsigned short* a0 = &Bs16[row * BN + 8 * ((col >> 3) ^ sw) + (col & 7)];
+                            const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+                            const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * BN));
+                            const s16x8 f = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                            bf[j] = __builtin_bit_cast(bf16x8, f);
+                        }
+                    }
 #pragma unroll
                     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -700,6 +722,8 @@ size_t cswin_linear_bwd_weight_workspace(int M, int N, int K) {
     return (size_t)(s0 > s1 ? s0 : s1) * ((size_t)N * K + N) * sizeof(float);
 }
 
+int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferred, void* stream);
+
 // dw[N,K] = (row_scale . dy)^T @ [x | x2];  dbias[N] = colsum(row_scale . dy)
 int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, int k_split, const float* row_scale,
                             int rows_per_sample, float* dw, float* dbias, void* workspace, size_t ws_bytes, int M,
@@ -710,6 +734,16 @@ int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, in
     size_t need = cswin_linear_bwd_weight_workspace(M, N, K);
     CSWIN_REQUIRE(workspace && ws_bytes >= need, CSWIN_ERR_WORKSPACE, "linear_bwd_weight: workspace %zu < %zu", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
+    if (g_matmul_precision == 1 && !x2 && N % 4 == 0 && K % 4 == 0 && aligned16(dy) && aligned16(x) && aligned16(workspace)) {
+        // bf16 mode: the transposing-read kernel (wgrad16.hip) through the batch entry, as a batch of one
+        cswin_wgrad_desc d1 = {dy, x, row_scale, dw, dbias, workspace, ws_bytes, rows_per_sample, M, N, K, 0};
+        cswin_reduce_job job;
+        int rc = cswin_linear_bwd_weight_batch(&d1, 1, &job, stream);
+        if (rc) return rc;
+        reduce_now_or_defer(job, deferred, st);
+        CSWIN_LAUNCH_CHECK();
+        return CSWIN_OK;
+    }
     int splits, rps;
     choose_split(M, N, K, &splits, &rps);
     // slab s = [dw partial (N*K) | dbias partial (N)]: one reduction launch serves both
@@ -773,7 +807,8 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
             const int M = d[i].M, N = d[i].N, K = d[i].K;
             const long slab = ((long)N * K + N) * (long)sizeof(float);
             const int tiles = cdiv(N, 128) * cdiv(K, 128);
-            int s = (768 / n) / tiles;
+            static const int w16_wgs = getenv("CSWIN_W16_WGS") ? atoi(getenv("CSWIN_W16_WGS")) : 768;      // tuning aid
+            int s = (w16_wgs / n) / tiles;
             const int cap = (int)(d[i].ws_bytes / slab);
             if (s > cap) s = cap;
             if (s > M / 64) s = M / 64;

@@ -971,6 +971,7 @@ def test_linear_weight_gradient_batch_bf16(bf16_matmul, shapes):
         got = dw.cpu()
         rms = float(ref32.pow(2).mean().sqrt())
         e16, e32 = float((got - ref16).abs().max()) / rms, float((got - ref32).abs().max()) / rms
-        assert e16 < 1e-4 and e32 < 1e-2, (i, shapes[i], e16, e32)
+        # max over up to 1e6 elements of an error with sigma = sqrt(2) * 2^-9 / sqrt(3) = 1.6e-3 of the RMS: 8 sigma
+        assert e16 < 1e-4 and e32 < 1.3e-2, (i, shapes[i], e16, e32)
         if db is not None:                                   # the bias gradient is summed in fp32 from the fp32 dy
             assert float((db.cpu() - db_ref).abs().max()) / float(db_ref.pow(2).mean().sqrt() + 1e-30) < 1e-4, i
