@@ -60,7 +60,7 @@ def attention_roofline(batch, cfg, img_size=224):
     Algorithmic FLOPs: QK^T + PV = 4*L*N*C per block per image forward; backward = 2x that (dQ, dK, dV, dP).
     Algorithmic bytes: q,k,v in + y out = 16*L*C per block per image forward; backward q,k,v,dy in + dqkv out = 28*L*C."""
     import ctypes
-    from cswin_unet_amd._lib import call, lib, ptr, stream
+    from cswin_unet_amd._lib import call, lib, ptr, stream, precision
     dev = "cuda"
     E, depth, heads, split = cfg.EMBED_DIM, cfg.DEPTH, cfg.NUM_HEADS, cfg.SPLIT_SIZE
     reso0 = img_size // 4
@@ -122,7 +122,7 @@ def gemm_family_roofline(batch, cfg, img_size=224):
     """The kernel family that dominates the step by time (~73 %): every Linear of the 26 CSWinBlocks, forward / data-gradient /
     weight-gradient, timed like the attention kernels (hipGraph replay between HIP events) through the C ABI and weighted by
     how often each shape runs in a step.  Algorithmic FLOPs = 2*M*N*K per GEMM."""
-    from cswin_unet_amd._lib import call, lib, ptr, stream
+    from cswin_unet_amd._lib import call, lib, ptr, stream, precision
     E, depth = cfg.EMBED_DIM, cfg.DEPTH
     reso0 = img_size // 4
     g = torch.Generator(device="cpu").manual_seed(11)
@@ -136,10 +136,10 @@ def gemm_family_roofline(batch, cfg, img_size=224):
             y, dx, dw, db = (torch.empty(*sh, device="cuda") for sh in ((M, N), (M, K), (N, K), (N,)))
             nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
             ws = torch.empty(nbytes // 4 + 4, device="cuda")
-            t = _graph_time(lambda: call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, stream()))
-            t += _graph_time(lambda: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, stream()))
+            t = _graph_time(lambda: call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, precision(), stream()))
+            t += _graph_time(lambda: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, precision(), stream()))
             t += _graph_time(lambda: call("cswin_linear_bwd_weight", ptr(dy), ptr(x), None, 0, None, 1, ptr(dw), ptr(db), ptr(ws), nbytes,
-                                          M, N, K, None, stream()))
+                                          M, N, K, None, precision(), stream()))
             tot_t += 2 * depth[si] * t
             tot_f += 2 * depth[si] * 3 * 2.0 * M * N * K
     achieved = tot_f / tot_t / 1e12

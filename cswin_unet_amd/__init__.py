@@ -13,15 +13,15 @@ _PRECISIONS = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 
 
 def set_matmul_precision(mode):
-    """"fp32" (default: exact fp32 MFMA) or "bf16" (bf16 operands, fp32 accumulate, fp32 storage) for every Linear /
-    convolution of the HIP path.  Returns the previous mode as a string."""
+    """"fp32" (default: exact fp32 MFMA) or "bf16" (bf16 operands, bf16 MFMA, fp32 accumulate and storage) for every Linear /
+    convolution issued through cswin_unet_amd.ops from now on.  The choice lives in this package and is passed to the library
+    with every call (the C ABI has no precision state).  Returns the previous mode as a string."""
+    from . import _lib
     if mode not in _PRECISIONS:
         raise ValueError(f"matmul precision {mode!r}: expected one of {sorted(_PRECISIONS)}")
-    prev = lib().cswin_set_matmul_precision(_PRECISIONS[mode])
-    if prev < 0:
-        raise CswinHipError(lib().cswin_last_error().decode())
-    return "bf16" if prev == 1 else "fp32"
+    return "bf16" if _lib.set_precision(_PRECISIONS[mode]) == 1 else "fp32"
 
 
 def get_matmul_precision():
-    return "bf16" if lib().cswin_get_matmul_precision() == 1 else "fp32"
+    from . import _lib
+    return "bf16" if _lib.precision() == 1 else "fp32"

@@ -20,8 +20,6 @@ SIGNATURES = {
     "cswin_last_error": (c_char_p, []),
     "cswin_abi_version": (I, []),
     "cswin_device_ok": (I, []),
-    "cswin_set_matmul_precision": (I, [I]),
-    "cswin_get_matmul_precision": (I, []),
     "cswin_attn_fwd": (I, [P, P, P, P, P, I, I, I, I, P, P, I, F, P]),
     "cswin_attn_bwd_workspace": (SZ, [I, I, I, I, P, P, I]),
     "cswin_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, I, I, P, P, I, F, P, P]),
@@ -30,16 +28,16 @@ SIGNATURES = {
     "cswin_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
     "cswin_layernorm_bwd_workspace": (SZ, [I, I]),
     "cswin_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, P, P]),
-    "cswin_linear_fwd": (I, [P, P, I, P, P, P, P, P, P, I, I, I, I, P]),
-    "cswin_linear_bwd_data": (I, [P, P, P, P, I, P, P, I, P, I, I, I, P]),
+    "cswin_linear_fwd": (I, [P, P, I, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "cswin_linear_bwd_data": (I, [P, P, P, P, I, P, P, I, P, I, I, I, I, P]),
     "cswin_linear_bwd_weight_workspace": (SZ, [I, I, I]),
-    "cswin_linear_bwd_weight": (I, [P, P, P, I, P, I, P, P, P, SZ, I, I, I, P, P]),
+    "cswin_linear_bwd_weight": (I, [P, P, P, I, P, I, P, P, P, SZ, I, I, I, P, I, P]),
     "cswin_linear_bwd_weight_batch": (I, [P, I, P, P]),
     "cswin_rows_sum_multi": (I, [P, I, P]),
-    "cswin_conv_tok_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
-    "cswin_conv_tok_bwd_data": (I, [P, P, P, I, I, I, I, I, I, I, I, P]),
+    "cswin_conv_tok_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "cswin_conv_tok_bwd_data": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "cswin_conv_tok_bwd_weight_workspace": (SZ, [I, I, I, I, I, I, I, I]),
-    "cswin_conv_tok_bwd_weight": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, I, I, I, P]),
+    "cswin_conv_tok_bwd_weight": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, I, I, I, I, P]),
     "cswin_conv_weight_permute": (I, [P, P, P, I, I, I, I, P]),
     "cswin_conv_weight_unpermute": (I, [P, P, I, I, I, I, P]),
     "cswin_conv_weight_flipT": (I, [P, P, I, I, I, P]),
@@ -65,7 +63,7 @@ class WgradDesc(ctypes.Structure):
     """Mirror of cswin_wgrad_desc (include/cswin_hip.h)."""
     _fields_ = [("dy", c_void_p), ("x", c_void_p), ("row_scale", c_void_p), ("dw", c_void_p), ("dbias", c_void_p),
                 ("workspace", c_void_p), ("ws_bytes", c_size_t), ("rows_per_sample", c_int), ("M", c_int), ("N", c_int),
-                ("K", c_int), ("reserved", c_int)]
+                ("K", c_int), ("precision", c_int)]
 
 
 class ReduceJob(ctypes.Structure):
@@ -75,6 +73,21 @@ class ReduceJob(ctypes.Structure):
 
 
 _lib = None
+
+# Matmul precision of the Linear / convolution entry points: an ARGUMENT of every call (0 = exact fp32 MFMA, 1 = bf16 operands,
+# bf16 MFMA, fp32 accumulate), not a library global.  The Python package keeps the caller's choice here and ops.py passes it.
+PREC_FP32, PREC_BF16 = 0, 1
+_state = {"precision": PREC_FP32}
+
+
+def precision():
+    return _state["precision"]
+
+
+def set_precision(mode):
+    prev = _state["precision"]
+    _state["precision"] = int(mode)
+    return prev
 
 
 class CswinHipError(RuntimeError):

@@ -197,7 +197,8 @@ typedef struct cswin_wgrad_desc {
     float* dbias;            // (N) or NULL
     void* workspace;         // cswin_linear_bwd_weight_workspace(M, N, K) bytes, 16-B aligned
     size_t ws_bytes;
-    int rows_per_sample, M, N, K, reserved;
+    int rows_per_sample, M, N, K;
+    int precision;           /* 0 = exact fp32 MFMA, 1 = bf16 operands (all problems of one launch agree) */
 } cswin_wgrad_desc;
 }
 

@@ -35,10 +35,10 @@ constexpr int BKMAX = 64;     // largest reduction tile (split sizes are multipl
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-// matmul precision of the whole family (cswin_set_matmul_precision): 0 = exact fp32 MFMA (default, the parity path);
+// matmul precision is an ARGUMENT of every entry point (no library state): 0 = exact fp32 MFMA (the parity path);
 // 1 = operands rounded to bf16 while they are staged into LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulation and fp32
-// storage everywhere (BASELINE configs 3-5 name bf16; this is the GEMM-input half of that)
-int g_matmul_precision = 0;
+// storage everywhere (BASELINE configs 3-5 name bf16)
+#define CSWIN_CHECK_PRECISION(p, who) CSWIN_REQUIRE((p) == 0 || (p) == 1, CSWIN_ERR_UNSUPPORTED, who ": precision %d (0 = fp32, 1 = bf16 operands)", (p))
 
 // ------------------------------------------------------------------------------------
 // operand sources: a logical matrix S(i, j) whose fast (contiguous) index is j
@@ -524,7 +524,7 @@ void launch_cfg(const ASrc& A, const BSrc& B, const Epilogue& epi, int M, int N,
 
 template <bool A_RC, bool B_RC, int VEC, int EPI, bool SCALE_A, class ASrc, class BSrc>
 void launch_gemm(const ASrc& A, const BSrc& B, const Epilogue& epi_in, int M, int N, int R, int splits, int r_per_split,
-                 hipStream_t st) {
+                 int precision, hipStream_t st) {
     Epilogue epi = epi_in;
     epi.vec_store = epilogue_vec_ok(epi, N);
     auto blocks = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(N, bn) * splits; };
@@ -542,7 +542,7 @@ void launch_gemm(const ASrc& A, const BSrc& B, const Epilogue& epi_in, int M, in
     if (splits == 1 && cost(64, 32, pen2) < cost(64, 64, 1.0)) tile = 2;
     if (forced_tile) tile = forced_tile;
     const int r_len = r_per_split < R ? r_per_split : R;
-    if (g_matmul_precision == 1) {
+    if (precision == 1) {
         // bf16 operands: 16x fewer MFMA cycles per tile, the kernel is bound by staging and barriers: one k-tile of 64,
         // and two wave groups only where a long reduction meets few workgroups
         const long nb = blocks(64, 64);
@@ -604,22 +604,13 @@ void choose_split(int M, int out_rows, int out_cols, int* splits, int* r_per_spl
 // ======================================================================================
 extern "C" {
 
-// 0: exact fp32 MFMA (default); 1: bf16 operands, fp32 accumulate (Linear and conv entry points).  Returns the previous mode,
-// or a negative error code for an unknown mode.  Process-wide: set it between steps, not concurrently with launches.
-int cswin_set_matmul_precision(int mode) {
-    CSWIN_REQUIRE(mode == 0 || mode == 1, CSWIN_ERR_UNSUPPORTED, "set_matmul_precision: mode %d (0 = fp32, 1 = bf16 operands)", mode);
-    const int prev = g_matmul_precision;
-    g_matmul_precision = mode;
-    return prev;
-}
-int cswin_get_matmul_precision(void) { return g_matmul_precision; }
-
 // debug aid (not part of include/cswin_hip.h): device buffer [nblk][4] of int64 that GEMM workgroups stamp with s_memtime
 void cswin_debug_set_stamps(void* p) { g_stamps = (long long*)p; }
 
 int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* w, const float* bias, float* y,
                      float* y_act, const float* residual, const float* row_scale, int rows_per_sample, int M, int N,
-                     int K, void* stream) {
+                     int K, int precision, void* stream) {
+    CSWIN_CHECK_PRECISION(precision, "linear_fwd");
     CSWIN_REQUIRE(x && w && y && M > 0 && N > 0 && K > 0, CSWIN_ERR_SHAPE, "linear_fwd: bad arguments M=%d N=%d K=%d", M, N, K);
     CSWIN_REQUIRE(!x2 || (k_split > 0 && k_split < K), CSWIN_ERR_SHAPE, "linear_fwd: bad concat split %d of K=%d", k_split, K);
     CSWIN_REQUIRE(!row_scale || rows_per_sample > 0, CSWIN_ERR_SHAPE, "linear_fwd: rows_per_sample must be > 0");
@@ -637,14 +628,14 @@ int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* 
         ConcatSrc A = {x, x2, k_split, K - k_split, M, K, k_split};
         bool vec = (k_split % 4 == 0) && (K % 4 == 0) && aligned16(x) && aligned16(x2) && aligned16(w);
         if (residual) {
-            if (vec) launch_gemm<true, true, 4, EPI_RES, false>(A, B, e, M, N, K, 1, rk, st);
-            else launch_gemm<true, true, 1, EPI_RES, false>(A, B, e, M, N, K, 1, rk, st);
+            if (vec) launch_gemm<true, true, 4, EPI_RES, false>(A, B, e, M, N, K, 1, rk, precision, st);
+            else launch_gemm<true, true, 1, EPI_RES, false>(A, B, e, M, N, K, 1, rk, precision, st);
         } else {
-            if (vec) launch_gemm<true, true, 4, EPI_PLAIN, false>(A, B, e, M, N, K, 1, rk, st);
-            else launch_gemm<true, true, 1, EPI_PLAIN, false>(A, B, e, M, N, K, 1, rk, st);
+            if (vec) launch_gemm<true, true, 4, EPI_PLAIN, false>(A, B, e, M, N, K, 1, rk, precision, st);
+            else launch_gemm<true, true, 1, EPI_PLAIN, false>(A, B, e, M, N, K, 1, rk, precision, st);
         }
     } else {
-        if (g_matmul_precision == 0) {
+        if (precision == 0) {
             const int rc = cswin_ws_gemm(0, y_act ? EPI_ACT : (residual ? EPI_RES : EPI_PLAIN), x, w, &e, M, N, K, stream);
             if (rc < 0) return rc;
             if (rc == 0) {
@@ -655,14 +646,14 @@ int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* 
         PlainSrc A = {x, K, M, K, nullptr, 1};
         bool vec = (K % 4 == 0) && aligned16(x) && aligned16(w);
         if (y_act) {
-            if (vec) launch_gemm<true, true, 4, EPI_ACT, false>(A, B, e, M, N, K, 1, rk, st);
-            else launch_gemm<true, true, 1, EPI_ACT, false>(A, B, e, M, N, K, 1, rk, st);
+            if (vec) launch_gemm<true, true, 4, EPI_ACT, false>(A, B, e, M, N, K, 1, rk, precision, st);
+            else launch_gemm<true, true, 1, EPI_ACT, false>(A, B, e, M, N, K, 1, rk, precision, st);
         } else if (residual) {
-            if (vec) launch_gemm<true, true, 4, EPI_RES, false>(A, B, e, M, N, K, 1, rk, st);
-            else launch_gemm<true, true, 1, EPI_RES, false>(A, B, e, M, N, K, 1, rk, st);
+            if (vec) launch_gemm<true, true, 4, EPI_RES, false>(A, B, e, M, N, K, 1, rk, precision, st);
+            else launch_gemm<true, true, 1, EPI_RES, false>(A, B, e, M, N, K, 1, rk, precision, st);
         } else {
-            if (vec) launch_gemm<true, true, 4, EPI_PLAIN, false>(A, B, e, M, N, K, 1, rk, st);
-            else launch_gemm<true, true, 1, EPI_PLAIN, false>(A, B, e, M, N, K, 1, rk, st);
+            if (vec) launch_gemm<true, true, 4, EPI_PLAIN, false>(A, B, e, M, N, K, 1, rk, precision, st);
+            else launch_gemm<true, true, 1, EPI_PLAIN, false>(A, B, e, M, N, K, 1, rk, precision, st);
         }
     }
     CSWIN_LAUNCH_CHECK();
@@ -672,7 +663,8 @@ int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* 
 // dx[M,K] = (row_scale . dy)[M,N] @ w[N,K]   (optionally * gelu'(gelu_pre), + add; optionally split into dx | dx2)
 int cswin_linear_bwd_data(const float* dy, const float* w, float* dx, float* dx2, int k_split, const float* gelu_pre,
                           const float* row_scale, int rows_per_sample, const float* add, int M, int N, int K,
-                          void* stream) {
+                          int precision, void* stream) {
+    CSWIN_CHECK_PRECISION(precision, "linear_bwd_data");
     CSWIN_REQUIRE(dy && w && dx && M > 0 && N > 0 && K > 0, CSWIN_ERR_SHAPE, "linear_bwd_data: bad arguments");
     CSWIN_REQUIRE(!dx2 || (k_split > 0 && k_split < K), CSWIN_ERR_SHAPE, "linear_bwd_data: bad concat split");
     CSWIN_REQUIRE(!row_scale || rows_per_sample > 0, CSWIN_ERR_SHAPE, "linear_bwd_data: rows_per_sample must be > 0");
@@ -689,7 +681,7 @@ int cswin_linear_bwd_data(const float* dy, const float* w, float* dx, float* dx2
     const int rn = cdiv(N, BKMAX) * BKMAX;
     const int modes = (dx2 != nullptr) + (gelu_pre != nullptr) + (add != nullptr);
     CSWIN_REQUIRE(modes <= 1, CSWIN_ERR_UNSUPPORTED, "linear_bwd_data: dx2 / gelu_pre / add are mutually exclusive");
-    if (!dx2 && g_matmul_precision == 0) {
+    if (!dx2 && precision == 0) {
         const int rc = cswin_ws_gemm(1, gelu_pre ? EPI_GELUBWD : (add ? EPI_RES : EPI_PLAIN), dy, w, &e, M, K, N, stream);
         if (rc < 0) return rc;
         if (rc == 0) {
@@ -698,17 +690,17 @@ int cswin_linear_bwd_data(const float* dy, const float* w, float* dx, float* dx2
         }
     }
     if (dx2) {
-        if (vec) launch_gemm<true, false, 4, EPI_SPLIT2, false>(A, B, e, M, K, N, 1, rn, st);
-        else launch_gemm<true, false, 1, EPI_SPLIT2, false>(A, B, e, M, K, N, 1, rn, st);
+        if (vec) launch_gemm<true, false, 4, EPI_SPLIT2, false>(A, B, e, M, K, N, 1, rn, precision, st);
+        else launch_gemm<true, false, 1, EPI_SPLIT2, false>(A, B, e, M, K, N, 1, rn, precision, st);
     } else if (gelu_pre) {
-        if (vec) launch_gemm<true, false, 4, EPI_GELUBWD, false>(A, B, e, M, K, N, 1, rn, st);
-        else launch_gemm<true, false, 1, EPI_GELUBWD, false>(A, B, e, M, K, N, 1, rn, st);
+        if (vec) launch_gemm<true, false, 4, EPI_GELUBWD, false>(A, B, e, M, K, N, 1, rn, precision, st);
+        else launch_gemm<true, false, 1, EPI_GELUBWD, false>(A, B, e, M, K, N, 1, rn, precision, st);
     } else if (add) {
-        if (vec) launch_gemm<true, false, 4, EPI_RES, false>(A, B, e, M, K, N, 1, rn, st);
-        else launch_gemm<true, false, 1, EPI_RES, false>(A, B, e, M, K, N, 1, rn, st);
+        if (vec) launch_gemm<true, false, 4, EPI_RES, false>(A, B, e, M, K, N, 1, rn, precision, st);
+        else launch_gemm<true, false, 1, EPI_RES, false>(A, B, e, M, K, N, 1, rn, precision, st);
     } else {
-        if (vec) launch_gemm<true, false, 4, EPI_PLAIN, false>(A, B, e, M, K, N, 1, rn, st);
-        else launch_gemm<true, false, 1, EPI_PLAIN, false>(A, B, e, M, K, N, 1, rn, st);
+        if (vec) launch_gemm<true, false, 4, EPI_PLAIN, false>(A, B, e, M, K, N, 1, rn, precision, st);
+        else launch_gemm<true, false, 1, EPI_PLAIN, false>(A, B, e, M, K, N, 1, rn, precision, st);
     }
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
@@ -727,16 +719,17 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
 // dw[N,K] = (row_scale . dy)^T @ [x | x2];  dbias[N] = colsum(row_scale . dy)
 int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, int k_split, const float* row_scale,
                             int rows_per_sample, float* dw, float* dbias, void* workspace, size_t ws_bytes, int M,
-                            int N, int K, cswin_reduce_job* deferred, void* stream) {
+                            int N, int K, cswin_reduce_job* deferred, int precision, void* stream) {
+    CSWIN_CHECK_PRECISION(precision, "linear_bwd_weight");
     CSWIN_REQUIRE(dy && x && dw && M > 0 && N > 0 && K > 0, CSWIN_ERR_SHAPE, "linear_bwd_weight: bad arguments");
     CSWIN_REQUIRE(!x2 || (k_split > 0 && k_split < K), CSWIN_ERR_SHAPE, "linear_bwd_weight: bad concat split");
     CSWIN_REQUIRE(!row_scale || rows_per_sample > 0, CSWIN_ERR_SHAPE, "linear_bwd_weight: rows_per_sample must be > 0");
     size_t need = cswin_linear_bwd_weight_workspace(M, N, K);
     CSWIN_REQUIRE(workspace && ws_bytes >= need, CSWIN_ERR_WORKSPACE, "linear_bwd_weight: workspace %zu < %zu", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
-    if (g_matmul_precision == 1 && !x2 && N % 4 == 0 && K % 4 == 0 && aligned16(dy) && aligned16(x) && aligned16(workspace)) {
+    if (precision == 1 && !x2 && N % 4 == 0 && K % 4 == 0 && aligned16(dy) && aligned16(x) && aligned16(workspace)) {
         // bf16 mode: the transposing-read kernel (wgrad16.hip) through the batch entry, as a batch of one
-        cswin_wgrad_desc d1 = {dy, x, row_scale, dw, dbias, workspace, ws_bytes, rows_per_sample, M, N, K, 0};
+        cswin_wgrad_desc d1 = {dy, x, row_scale, dw, dbias, workspace, ws_bytes, rows_per_sample, M, N, K, 1};
         cswin_reduce_job job;
         int rc = cswin_linear_bwd_weight_batch(&d1, 1, &job, stream);
         if (rc) return rc;
@@ -757,17 +750,17 @@ int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, in
     if (x2) {
         ConcatSrc B = {x, x2, k_split, K - k_split, M, K, k_split};
         bool vec = (N % 4 == 0) && (K % 4 == 0) && (k_split % 4 == 0) && aligned16(dy) && aligned16(x) && aligned16(x2);
-        if (vec) launch_gemm<false, false, 4, EPI_PLAIN, true>(A, B, e, N, K, M, splits, rps, st);
-        else launch_gemm<false, false, 1, EPI_PLAIN, true>(A, B, e, N, K, M, splits, rps, st);
+        if (vec) launch_gemm<false, false, 4, EPI_PLAIN, true>(A, B, e, N, K, M, splits, rps, precision, st);
+        else launch_gemm<false, false, 1, EPI_PLAIN, true>(A, B, e, N, K, M, splits, rps, precision, st);
     } else {
         PlainSrc B = {x, K, M, K, nullptr, 1};
         bool vec = (N % 4 == 0) && (K % 4 == 0) && aligned16(dy) && aligned16(x);
         if (row_scale) {
-            if (vec) launch_gemm<false, false, 4, EPI_PLAIN, true>(A, B, e, N, K, M, splits, rps, st);
-            else launch_gemm<false, false, 1, EPI_PLAIN, true>(A, B, e, N, K, M, splits, rps, st);
+            if (vec) launch_gemm<false, false, 4, EPI_PLAIN, true>(A, B, e, N, K, M, splits, rps, precision, st);
+            else launch_gemm<false, false, 1, EPI_PLAIN, true>(A, B, e, N, K, M, splits, rps, precision, st);
         } else {
-            if (vec) launch_gemm<false, false, 4, EPI_PLAIN, false>(A, B, e, N, K, M, splits, rps, st);
-            else launch_gemm<false, false, 1, EPI_PLAIN, false>(A, B, e, N, K, M, splits, rps, st);
+            if (vec) launch_gemm<false, false, 4, EPI_PLAIN, false>(A, B, e, N, K, M, splits, rps, precision, st);
+            else launch_gemm<false, false, 1, EPI_PLAIN, false>(A, B, e, N, K, M, splits, rps, precision, st);
         }
     }
     CSWIN_LAUNCH_CHECK();
@@ -784,7 +777,10 @@ int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, in
 int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferred, void* stream) {
     CSWIN_REQUIRE(d && deferred && n >= 1 && n <= WGRAD_BATCH, CSWIN_ERR_SHAPE, "linear_bwd_weight_batch: 1..%d problems and their deferred slots", WGRAD_BATCH);
     bool fast = true;
+    const int precision = d[0].precision;
+    CSWIN_CHECK_PRECISION(precision, "linear_bwd_weight_batch");
     for (int i = 0; i < n; ++i) {
+        CSWIN_REQUIRE(d[i].precision == precision, CSWIN_ERR_UNSUPPORTED, "linear_bwd_weight_batch: problems of one launch share one precision");
         CSWIN_REQUIRE(d[i].dy && d[i].x && d[i].dw && d[i].M > 0 && d[i].N > 0 && d[i].K > 0, CSWIN_ERR_SHAPE, "linear_bwd_weight_batch: bad problem %d", i);
         CSWIN_REQUIRE(!d[i].row_scale || d[i].rows_per_sample > 0, CSWIN_ERR_SHAPE, "linear_bwd_weight_batch: rows_per_sample must be > 0");
         size_t need = cswin_linear_bwd_weight_workspace(d[i].M, d[i].N, d[i].K);
@@ -794,13 +790,13 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
     if (!fast) {
         for (int i = 0; i < n; ++i) {
             int rc = cswin_linear_bwd_weight(d[i].dy, d[i].x, nullptr, 0, d[i].row_scale, d[i].rows_per_sample, d[i].dw, d[i].dbias,
-                                             d[i].workspace, d[i].ws_bytes, d[i].M, d[i].N, d[i].K, &deferred[i], stream);
+                                             d[i].workspace, d[i].ws_bytes, d[i].M, d[i].N, d[i].K, &deferred[i], precision, stream);
             if (rc) return rc;
         }
         return CSWIN_OK;
     }
     static const int w16_off = getenv("CSWIN_WGRAD16") ? atoi(getenv("CSWIN_WGRAD16")) == 0 : 0;     // tuning aid
-    if (g_matmul_precision == 1 && !w16_off) {
+    if (precision == 1 && !w16_off) {
         // bf16 operands: 128 x 128 tiles, ~3 workgroups per CU over the whole batch (load-bound: see wgrad16.hip)
         int splits[WGRAD_BATCH], rps[WGRAD_BATCH];
         for (int i = 0; i < n; ++i) {
@@ -853,7 +849,7 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
     }
     b.first[n] = blocks;
     b.n = n;
-    if (g_matmul_precision == 1) hipLaunchKernelGGL(gemm_wgrad_batch_kernel<1>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, b);
+    if (precision == 1) hipLaunchKernelGGL(gemm_wgrad_batch_kernel<1>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, b);
     else hipLaunchKernelGGL(gemm_wgrad_batch_kernel<0>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, b);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
@@ -862,7 +858,8 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
 // -------- convolutions on the (B, H*W, C) token layout (NHWC), implicit GEMM -----------------------------------
 // w_perm: [Cout][ks*ks][Cin]  (made by cswin_conv_weight_permute from the nn.Conv2d [Cout][Cin][ks][ks] parameter)
 int cswin_conv_tok_fwd(const float* x, const float* w_perm, const float* bias, float* y, int B, int H, int W, int Cin,
-                       int Cout, int ks, int stride, int pad, void* stream) {
+                       int Cout, int ks, int stride, int pad, int precision, void* stream) {
+    CSWIN_CHECK_PRECISION(precision, "conv_tok_fwd");
     CSWIN_REQUIRE(x && w_perm && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, CSWIN_ERR_SHAPE, "conv_tok_fwd: bad arguments");
     CSWIN_REQUIRE(Cin % 4 == 0 && aligned16(x) && aligned16(w_perm), CSWIN_ERR_ALIGN, "conv_tok_fwd: Cin %% 4 and 16-B alignment required");
     int OH = (H + 2 * pad - ks) / stride + 1, OW = (W + 2 * pad - ks) / stride + 1;
@@ -871,14 +868,15 @@ int cswin_conv_tok_fwd(const float* x, const float* w_perm, const float* bias, f
     PlainSrc Bm = {w_perm, R, Cout, R, nullptr, 1};
     Epilogue e = plain_epilogue(y, Cout);
     e.bias = bias;
-    launch_gemm<true, true, 4, EPI_PLAIN, false>(A, Bm, e, M, Cout, R, 1, cdiv(R, BKMAX) * BKMAX, (hipStream_t)stream);
+    launch_gemm<true, true, 4, EPI_PLAIN, false>(A, Bm, e, M, Cout, R, 1, cdiv(R, BKMAX) * BKMAX, precision, (hipStream_t)stream);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }
 
 // w_permT: [ks*ks][Cout][Cin]
 int cswin_conv_tok_bwd_data(const float* dy, const float* w_permT, float* dx, int B, int H, int W, int Cin, int Cout,
-                            int ks, int stride, int pad, void* stream) {
+                            int ks, int stride, int pad, int precision, void* stream) {
+    CSWIN_CHECK_PRECISION(precision, "conv_tok_bwd_data");
     CSWIN_REQUIRE(dy && w_permT && dx, CSWIN_ERR_SHAPE, "conv_tok_bwd_data: null pointer");
     CSWIN_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0 && aligned16(dy) && aligned16(w_permT), CSWIN_ERR_ALIGN, "conv_tok_bwd_data: channels %% 4 and 16-B alignment required");
     int OH = (H + 2 * pad - ks) / stride + 1, OW = (W + 2 * pad - ks) / stride + 1;
@@ -919,7 +917,7 @@ int cswin_conv_tok_bwd_data(const float* dy, const float* w_permT, float* dx, in
             hipStream_t st = (hipStream_t)stream;
             // few workgroups and a long reduction: split each k-tile over wave groups (same rule as launch_gemm)
             const int kw = (blocks < 320 && rmax >= 512) ? 4 : ((blocks < 640 && rmax >= 256) ? 2 : 1);
-            if (g_matmul_precision == 1) {
+            if (precision == 1) {
                 hipLaunchKernelGGL((gemm_conv_s2_dgrad_batch_kernel<2, 1>), dim3(blocks), dim3(512), 0, st, b);
             } else if (kw == 4) {
                 hipLaunchKernelGGL((gemm_conv_s2_dgrad_batch_kernel<4, 0>), dim3(blocks), dim3(1024), 0, st, b);
@@ -936,7 +934,7 @@ int cswin_conv_tok_bwd_data(const float* dy, const float* w_permT, float* dx, in
     ConvTSrc A = {dy, B, H, W, Cout, OH, OW, ks, stride, pad, M, R};
     PlainSrc Bm = {w_permT, Cin, R, Cin, nullptr, 1};          // S(i = (tap, co), j = ci)
     Epilogue e = plain_epilogue(dx, Cin);
-    launch_gemm<true, false, 4, EPI_PLAIN, false>(A, Bm, e, M, Cin, R, 1, cdiv(R, BKMAX) * BKMAX, (hipStream_t)stream);
+    launch_gemm<true, false, 4, EPI_PLAIN, false>(A, Bm, e, M, Cin, R, 1, cdiv(R, BKMAX) * BKMAX, precision, (hipStream_t)stream);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }
@@ -949,7 +947,8 @@ size_t cswin_conv_tok_bwd_weight_workspace(int B, int H, int W, int Cin, int Cou
 // dw_perm: [Cout][ks*ks][Cin], or the nn.Conv2d parameter layout [Cout][Cin][ks][ks] when torch_layout != 0; dbias: [Cout]
 int cswin_conv_tok_bwd_weight(const float* dy, const float* x, float* dw_perm, float* dbias, void* workspace,
                               size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ks, int stride, int pad,
-                              int torch_layout, void* stream) {
+                              int torch_layout, int precision, void* stream) {
+    CSWIN_CHECK_PRECISION(precision, "conv_tok_bwd_weight");
     CSWIN_REQUIRE(dy && x && dw_perm, CSWIN_ERR_SHAPE, "conv_tok_bwd_weight: null pointer");
     CSWIN_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0 && aligned16(dy) && aligned16(x), CSWIN_ERR_ALIGN, "conv_tok_bwd_weight: channels %% 4 and 16-B alignment required");
     int OH = (H + 2 * pad - ks) / stride + 1, OW = (W + 2 * pad - ks) / stride + 1;
@@ -967,7 +966,7 @@ int cswin_conv_tok_bwd_weight(const float* dy, const float* x, float* dw_perm, f
     e.colsum_stride = (int)slab_stride;
     PlainSrc A = {dy, Cout, M, Cout, nullptr, 1};
     ConvSrc Bm = {x, B, H, W, Cin, OH, OW, ks, stride, pad, M, K};   // S(i = pixel m (reduction), j = (tap, ci))
-    launch_gemm<false, false, 4, EPI_PLAIN, false>(A, Bm, e, Cout, K, M, splits, rps, st);
+    launch_gemm<false, false, 4, EPI_PLAIN, false>(A, Bm, e, Cout, K, M, splits, rps, precision, st);
     CSWIN_LAUNCH_CHECK();
     long n = (long)Cout * K;
     if (torch_layout) {

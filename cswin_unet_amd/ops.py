@@ -10,7 +10,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from ._lib import ReduceJob, WgradDesc, call, dev_f32, lib, ptr, stream
+from ._lib import ReduceJob, WgradDesc, call, dev_f32, lib, precision, ptr, stream
 
 __all__ = ["layer_norm", "linear", "linear_pair", "mlp", "stripe_attention", "cswin_block", "conv_tokens", "patch_embed_conv", "carafe_reassemble",
            "tokens_to_nchw", "matmul_nn", "ce_dice_loss", "dropout", "img2windows", "windows2img"]
@@ -141,7 +141,7 @@ class _Linear(Function):
         y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
         rps = _rows_per_sample(x) if row_scale is not None else 1
         call("cswin_linear_fwd", ptr(x), ptr(x2), K1 if x2 is not None else 0, ptr(w), ptr(b), ptr(y), None, ptr(residual),
-             ptr(row_scale), rps, M, N, K, stream())
+             ptr(row_scale), rps, M, N, K, precision(), stream())
         ctx.save_for_backward(x, w, x2, row_scale)
         ctx.has_bias, ctx.has_res, ctx.rps = b is not None, residual is not None, rps
         return y
@@ -160,7 +160,7 @@ class _Linear(Function):
             dx = torch.empty_like(x)
             dx2 = torch.empty_like(x2) if x2 is not None else None
             call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), ptr(dx2), K1 if x2 is not None else 0, None,
-                 ptr(row_scale), ctx.rps, None, M, N, K, stream())
+                 ptr(row_scale), ctx.rps, None, M, N, K, precision(), stream())
         if need[1]:
             with _side_stream(dy, x, x2, row_scale):
                 dw = torch.empty_like(w)
@@ -168,7 +168,7 @@ class _Linear(Function):
                 nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
                 ws = _ws(nbytes, w.device)
                 call("cswin_linear_bwd_weight", ptr(dy), ptr(x), ptr(x2), K1 if x2 is not None else 0, ptr(row_scale), ctx.rps,
-                     ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, None, stream())
+                     ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, None, precision(), stream())
         dres = dy if ctx.has_res else None
         return dx, dw, db, dx2, dres, None
 
@@ -192,7 +192,7 @@ class _LinearPair(Function):
         for w, b in ((w1, b1), (w2, b2)):
             assert w.shape[1] == K
             y = torch.empty(x.shape[:-1] + (w.shape[0],), dtype=torch.float32, device=x.device)
-            call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, w.shape[0], K, stream())
+            call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, w.shape[0], K, precision(), stream())
             ys.append(y)
         ctx.save_for_backward(x, w1, w2)
         ctx.has_b = (b1 is not None, b2 is not None)
@@ -209,8 +209,8 @@ class _LinearPair(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            call("cswin_linear_bwd_data", ptr(dy1), ptr(w1), ptr(dx), None, 0, None, None, 1, None, M, w1.shape[0], K, st)
-            call("cswin_linear_bwd_data", ptr(dy2), ptr(w2), ptr(dx), None, 0, None, None, 1, ptr(dx), M, w2.shape[0], K, st)
+            call("cswin_linear_bwd_data", ptr(dy1), ptr(w1), ptr(dx), None, 0, None, None, 1, None, M, w1.shape[0], K, precision(), st)
+            call("cswin_linear_bwd_data", ptr(dy2), ptr(w2), ptr(dx), None, 0, None, None, 1, ptr(dx), M, w2.shape[0], K, precision(), st)
         grads, keep = [], []
         wg, jobs = (WgradDesc * 2)(), (ReduceJob * 2)()
         for i, (dy, w, has_b) in enumerate(((dy1, w1, ctx.has_b[0]), (dy2, w2, ctx.has_b[1]))):
@@ -222,7 +222,7 @@ class _LinearPair(Function):
             keep.append(ws)
             wg[i].dy, wg[i].x, wg[i].row_scale, wg[i].dw = dy.data_ptr(), x.data_ptr(), None, dw.data_ptr()
             wg[i].dbias, wg[i].workspace, wg[i].ws_bytes = (db.data_ptr() if has_b else None), ws.data_ptr(), nbytes
-            wg[i].rows_per_sample, wg[i].M, wg[i].N, wg[i].K = 1, M, N, K
+            wg[i].rows_per_sample, wg[i].M, wg[i].N, wg[i].K, wg[i].precision = 1, M, N, K, precision()
             grads += [dw, db]
         call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 2, ctypes.cast(jobs, ctypes.c_void_p), st)
         call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), 2, st)
@@ -248,17 +248,17 @@ class _Mlp(Function):
         M = x.numel() // K
         pre = torch.empty(x.shape[:-1] + (Hd,), dtype=torch.float32, device=x.device)
         act = torch.empty_like(pre)
-        call("cswin_linear_fwd", ptr(x), None, 0, ptr(w1), ptr(b1), ptr(pre), ptr(act), None, None, 1, M, Hd, K, stream())
+        call("cswin_linear_fwd", ptr(x), None, 0, ptr(w1), ptr(b1), ptr(pre), ptr(act), None, None, 1, M, Hd, K, precision(), stream())
         y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
         rps = _rows_per_sample(x) if row_scale is not None else 1
         if drop_p > 0:
             call("cswin_dropout", ptr(act), None, None, ptr(act), act.numel(), act.numel() // act.shape[0], drop_p, seeds[0], stream())
-            call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(b2), ptr(y), None, None, None, 1, M, N, Hd, stream())
+            call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(b2), ptr(y), None, None, None, 1, M, N, Hd, precision(), stream())
             call("cswin_dropout", ptr(y), ptr(residual), ptr(row_scale), ptr(y), y.numel(), y.numel() // y.shape[0], drop_p, seeds[1],
                  stream())
         else:
             call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(b2), ptr(y), None, ptr(residual), ptr(row_scale), rps,
-                 M, N, Hd, stream())
+                 M, N, Hd, precision(), stream())
         ctx.save_for_backward(x, w1, w2, pre, act, row_scale)
         ctx.has_res, ctx.rps, ctx.has_b1, ctx.has_b2 = residual is not None, rps, b1 is not None, b2 is not None
         ctx.drop = (float(drop_p), seeds)
@@ -283,23 +283,23 @@ class _Mlp(Function):
         # d pre = (row_scale * dy @ w2) * gelu'(pre)   (GELU backward fused into the data-gradient epilogue)
         dpre = torch.empty_like(pre)
         call("cswin_linear_bwd_data", ptr(dyl), ptr(w2), ptr(dpre), None, 0, ptr(pre), ptr(rs_gemm), ctx.rps, None, M, N,
-             Hd, st)
+             Hd, precision(), st)
         if drop_p > 0:
             call("cswin_dropout", ptr(dpre), None, None, ptr(dpre), dpre.numel(), dpre.numel() // dpre.shape[0], drop_p, seeds[0], st)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            call("cswin_linear_bwd_data", ptr(dpre), ptr(w1), ptr(dx), None, 0, None, None, 1, None, M, Hd, K, st)
+            call("cswin_linear_bwd_data", ptr(dpre), ptr(w1), ptr(dx), None, 0, None, None, 1, None, M, Hd, K, precision(), st)
         with _side_stream(dyl, act, dpre, x, rs_gemm):          # both weight gradients, off the data-gradient chain
             dw2 = torch.empty_like(w2)
             db2 = torch.empty(N, dtype=torch.float32, device=dev) if ctx.has_b2 else None
             nbytes = max(lib().cswin_linear_bwd_weight_workspace(M, N, Hd), lib().cswin_linear_bwd_weight_workspace(M, Hd, K))
             ws = _ws(nbytes, dev)
             call("cswin_linear_bwd_weight", ptr(dyl), ptr(act), None, 0, ptr(rs_gemm), ctx.rps, ptr(dw2), ptr(db2), ptr(ws),
-                 nbytes, M, N, Hd, None, stream())
+                 nbytes, M, N, Hd, None, precision(), stream())
             dw1 = torch.empty_like(w1)
             db1 = torch.empty(Hd, dtype=torch.float32, device=dev) if ctx.has_b1 else None
-            call("cswin_linear_bwd_weight", ptr(dpre), ptr(x), None, 0, None, 1, ptr(dw1), ptr(db1), ptr(ws), nbytes, M, Hd, K, None, stream())
+            call("cswin_linear_bwd_weight", ptr(dpre), ptr(x), None, 0, None, 1, ptr(dw1), ptr(db1), ptr(ws), nbytes, M, Hd, K, None, precision(), stream())
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None, None, None
 
 
@@ -320,7 +320,7 @@ class _MatmulNN(Function):
         M, N = a.shape
         K = b.shape[1]
         c = torch.empty(M, K, dtype=torch.float32, device=a.device)
-        call("cswin_linear_bwd_data", ptr(a), ptr(b), ptr(c), None, 0, None, None, 1, None, M, N, K, stream())
+        call("cswin_linear_bwd_data", ptr(a), ptr(b), ptr(c), None, 0, None, None, 1, None, M, N, K, precision(), stream())
         ctx.save_for_backward(a, b)
         return c
 
@@ -332,11 +332,11 @@ class _MatmulNN(Function):
         M, N = a.shape
         K = b.shape[1]
         da = torch.empty_like(a)        # da = dc @ b^T
-        call("cswin_linear_fwd", ptr(dc), None, 0, ptr(b), None, ptr(da), None, None, None, 1, M, N, K, stream())
+        call("cswin_linear_fwd", ptr(dc), None, 0, ptr(b), None, ptr(da), None, None, None, 1, M, N, K, precision(), stream())
         db = torch.empty_like(b)        # db (N, K) = a^T @ dc
         nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
         ws = _ws(nbytes, a.device)
-        call("cswin_linear_bwd_weight", ptr(a), ptr(dc), None, 0, None, 1, ptr(db), None, ptr(ws), nbytes, M, N, K, None, stream())
+        call("cswin_linear_bwd_weight", ptr(a), ptr(dc), None, 0, None, 1, ptr(db), None, ptr(ws), nbytes, M, N, K, None, precision(), stream())
         return da, db
 
 
@@ -419,20 +419,20 @@ class _CSWinBlock(Function):
         h1, m1, r1 = torch.empty_like(x), E(M), E(M)
         call("cswin_layernorm_fwd", ptr(x), ptr(g1), ptr(b1), ptr(h1), ptr(m1), ptr(r1), M, C, eps1, st)
         qkv = E(B, L, 3 * C)
-        call("cswin_linear_fwd", ptr(h1), None, 0, ptr(wqkv), ptr(bqkv), ptr(qkv), None, None, None, 1, M, 3 * C, C, st)
+        call("cswin_linear_fwd", ptr(h1), None, 0, ptr(wqkv), ptr(bqkv), ptr(qkv), None, None, None, 1, M, 3 * C, C, precision(), st)
         att, lse = E(B, L, C), E(B, sum(heads), L)
         ha, ia = _int_array(heads), _int_array(idx)
         call("cswin_attn_fwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(att), ptr(lse), B, reso, C, nb, ha, ia, split,
              float(scale or 0.0), st)
         x1 = torch.empty_like(x)
-        call("cswin_linear_fwd", ptr(att), None, 0, ptr(wp), ptr(bp), ptr(x1), None, ptr(x), ptr(rs1), L, M, C, C, st)
+        call("cswin_linear_fwd", ptr(att), None, 0, ptr(wp), ptr(bp), ptr(x1), None, ptr(x), ptr(rs1), L, M, C, C, precision(), st)
         h2, m2, r2 = torch.empty_like(x), E(M), E(M)
         call("cswin_layernorm_fwd", ptr(x1), ptr(g2), ptr(b2), ptr(h2), ptr(m2), ptr(r2), M, C, eps2, st)
         Hd = w1.shape[0]
         pre, act = E(B, L, Hd), E(B, L, Hd)
-        call("cswin_linear_fwd", ptr(h2), None, 0, ptr(w1), ptr(bb1), ptr(pre), ptr(act), None, None, 1, M, Hd, C, st)
+        call("cswin_linear_fwd", ptr(h2), None, 0, ptr(w1), ptr(bb1), ptr(pre), ptr(act), None, None, 1, M, Hd, C, precision(), st)
         y = torch.empty_like(x)
-        call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(bb2), ptr(y), None, ptr(x1), ptr(rs2), L, M, C, Hd, st)
+        call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(bb2), ptr(y), None, ptr(x1), ptr(rs2), L, M, C, Hd, precision(), st)
         ctx.save_for_backward(x, m1, r1, h1, qkv, lse, att, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lw, *lb)
         ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0), bqkv is not None)
         return y
@@ -460,7 +460,7 @@ class _CSWinBlock(Function):
         J = lambda i: ctypes.cast(ctypes.byref(jobs[i]), ctypes.c_void_p)
         # ---- MLP branch ----
         dpre = torch.empty_like(pre)
-        call("cswin_linear_bwd_data", ptr(dy), ptr(w2), ptr(dpre), None, 0, ptr(pre), ptr(rs2), L, None, M, C, Hd, st)
+        call("cswin_linear_bwd_data", ptr(dy), ptr(w2), ptr(dpre), None, 0, ptr(pre), ptr(rs2), L, None, M, C, Hd, precision(), st)
         # the four weight gradients are off the critical path: they run as ONE batched launch once all operands exist
         wg = (WgradDesc * 4)()
 
@@ -468,20 +468,20 @@ class _CSWinBlock(Function):
             wg[slot].dy, wg[slot].x, wg[slot].row_scale = dy_.data_ptr(), x_.data_ptr(), (rs_.data_ptr() if rs_ is not None else None)
             wg[slot].dw, wg[slot].dbias = dw_.data_ptr(), (db_.data_ptr() if db_ is not None else None)
             wg[slot].workspace, wg[slot].ws_bytes = wsp[wsi].value, sizes[wsi]
-            wg[slot].rows_per_sample, wg[slot].M, wg[slot].N, wg[slot].K = L, M, N_, K_
+            wg[slot].rows_per_sample, wg[slot].M, wg[slot].N, wg[slot].K, wg[slot].precision = L, M, N_, K_, precision()
 
         dw2, db2 = torch.empty_like(w2), E(C)
         defer_wgrad(0, dy, act, rs2, dw2, db2, 0, C, Hd)
         dw1, db1 = torch.empty_like(w1), E(Hd)
         defer_wgrad(1, dpre, h2, None, dw1, db1, 1, Hd, C)
         dh2 = torch.empty_like(x)
-        call("cswin_linear_bwd_data", ptr(dpre), ptr(w1), ptr(dh2), None, 0, None, None, 1, None, M, Hd, C, st)
+        call("cswin_linear_bwd_data", ptr(dpre), ptr(w1), ptr(dh2), None, 0, None, None, 1, None, M, Hd, C, precision(), st)
         dx1, dg2, dbt2 = torch.empty_like(x), E(C), E(C)
         call("cswin_layernorm_bwd", ptr(dh2), ptr(x1), ptr(m2), ptr(r2), ptr(g2), ptr(dy), ptr(dx1), ptr(dg2), ptr(dbt2), wsp[2],
              sizes[2], M, C, J(2), st)
         # ---- attention branch ----
         datt = dh2                                                     # reuse
-        call("cswin_linear_bwd_data", ptr(dx1), ptr(wp), ptr(datt), None, 0, None, ptr(rs1), L, None, M, C, C, st)
+        call("cswin_linear_bwd_data", ptr(dx1), ptr(wp), ptr(datt), None, 0, None, ptr(rs1), L, None, M, C, C, precision(), st)
         dwp, dbp = torch.empty_like(wp), E(C)
         defer_wgrad(2, dx1, att, rs1, dwp, dbp, 3, C, C)
         early = None
@@ -516,7 +516,7 @@ class _CSWinBlock(Function):
         for slot, ji in enumerate((0, 1, 3, 4)):
             jobs[ji] = wjobs[slot]
         dh1 = datt                                                     # reuse again
-        call("cswin_linear_bwd_data", ptr(dqkv), ptr(wqkv), ptr(dh1), None, 0, None, None, 1, None, M, 3 * C, C, st)
+        call("cswin_linear_bwd_data", ptr(dqkv), ptr(wqkv), ptr(dh1), None, 0, None, None, 1, None, M, 3 * C, C, precision(), st)
         dx, dg1, dbt1 = torch.empty_like(x), E(C), E(C)
         call("cswin_layernorm_bwd", ptr(dh1), ptr(x), ptr(m1), ptr(r1), ptr(g1), ptr(dx1), ptr(dx), ptr(dg1), ptr(dbt1), wsp[5],
              sizes[5], M, C, J(5), st)
@@ -559,7 +559,7 @@ class _ConvTokens(Function):
         same = stride == 1 and 2 * pad == ks - 1 and Cout % 4 == 0
         wp, wpt = _permute_w(w, Cin, need_dx and not same)   # both weight images in one launch; the transposed one is kept
         y = torch.empty(B, OH * OW, Cout, dtype=torch.float32, device=x.device)
-        call("cswin_conv_tok_fwd", ptr(x), ptr(wp), ptr(b), ptr(y), B, H, W, Cin, Cout, ks, stride, pad, stream())
+        call("cswin_conv_tok_fwd", ptr(x), ptr(wp), ptr(b), ptr(y), B, H, W, Cin, Cout, ks, stride, pad, precision(), stream())
         ctx.save_for_backward(x, w, wpt)
         ctx.meta = (H, W, stride, pad, b is not None)
         return y
@@ -581,18 +581,18 @@ class _ConvTokens(Function):
                 # the generic transposed gather (CARAFE4 encoder, 16 -> 144 channels at 56 x 56: 13.41 -> 13.36 ms per step)
                 wf = torch.empty(Cin, ks * ks, Cout, dtype=torch.float32, device=x.device)
                 call("cswin_conv_weight_flipT", ptr(w), ptr(wf), Cout, Cin, ks, st)
-                call("cswin_conv_tok_fwd", ptr(dy), ptr(wf), None, ptr(dx), B, H, W, Cout, Cin, ks, 1, pad, st)
+                call("cswin_conv_tok_fwd", ptr(dy), ptr(wf), None, ptr(dx), B, H, W, Cout, Cin, ks, 1, pad, precision(), st)
             else:
                 if wpt is None:
                     _, wpt = _permute_w(w, Cin, True)
-                call("cswin_conv_tok_bwd_data", ptr(dy), ptr(wpt), ptr(dx), B, H, W, Cin, Cout, ks, stride, pad, st)
+                call("cswin_conv_tok_bwd_data", ptr(dy), ptr(wpt), ptr(dx), B, H, W, Cin, Cout, ks, stride, pad, precision(), st)
         with _side_stream(dy, x):
             dw = torch.empty_like(w)                    # written in the parameter layout by the slab reduction itself
             db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_b else None
             nbytes = lib().cswin_conv_tok_bwd_weight_workspace(B, H, W, Cin, Cout, ks, stride, pad)
             ws = _ws(nbytes, x.device)
             call("cswin_conv_tok_bwd_weight", ptr(dy), ptr(x), ptr(dw), ptr(db), ptr(ws), nbytes, B, H, W, Cin, Cout, ks,
-                 stride, pad, 1, stream())
+                 stride, pad, 1, precision(), stream())
         return dx, dw, db, None, None, None, None
 
 
@@ -616,7 +616,7 @@ class _PatchEmbedConv(Function):
         wp, _ = _permute_w(w, cpad, False)
         OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
         y = torch.empty(B, OH * OW, Cout, dtype=torch.float32, device=img.device)
-        call("cswin_conv_tok_fwd", ptr(x), ptr(wp), ptr(b), ptr(y), B, H, W, cpad, Cout, ks, stride, pad, st)
+        call("cswin_conv_tok_fwd", ptr(x), ptr(wp), ptr(b), ptr(y), B, H, W, cpad, Cout, ks, stride, pad, precision(), st)
         ctx.save_for_backward(x, w)
         ctx.meta = (H, W, stride, pad, cpad, b is not None)
         return y
@@ -635,7 +635,7 @@ class _PatchEmbedConv(Function):
         nbytes = lib().cswin_conv_tok_bwd_weight_workspace(B, H, W, cpad, Cout, ks, stride, pad)
         ws = _ws(nbytes, x.device)
         call("cswin_conv_tok_bwd_weight", ptr(dy), ptr(x), ptr(dwp), ptr(db), ptr(ws), nbytes, B, H, W, cpad, Cout, ks, stride,
-             pad, 0, st)                                # channel-padded image (3 -> 4): unpermuted separately
+             pad, 0, precision(), st)                                # channel-padded image (3 -> 4): unpermuted separately
         dw = torch.empty_like(w)
         call("cswin_conv_weight_unpermute", ptr(dwp), ptr(dw), Cout, Cin, ks, cpad, st)
         return None, dw, db, None, None

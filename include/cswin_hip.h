@@ -46,12 +46,11 @@ typedef struct cswin_reduce_job {
 const char* cswin_last_error(void);
 int cswin_abi_version(void);
 int cswin_device_ok(void); /* 1 if the current HIP device is gfx950 */
-/* Matmul precision of the Linear and convolution entry points: 0 = exact fp32 MFMA (default; the parity path of BASELINE
- * configs[1]); 1 = operands rounded to bf16 while staged into LDS, bf16 MFMA, fp32 accumulation, fp32 tensors in HBM (the
- * "bf16" of BASELINE configs[2..4] as far as the GEMMs go; torch.autocast(bfloat16) on the reference's Linear / Conv2d is the
- * closest reference-side equivalent).  Process-wide; returns the previous mode or a negative error code. */
-int cswin_set_matmul_precision(int mode);
-int cswin_get_matmul_precision(void);
+/* `precision` argument of the Linear and convolution entry points (and field of cswin_wgrad_desc): 0 = exact fp32 MFMA (the
+ * parity path of BASELINE configs[1]); 1 = operands rounded to bf16 while staged into LDS, bf16 MFMA, fp32 accumulation, fp32
+ * tensors in HBM (the "bf16" of BASELINE configs[2..4] as far as the GEMMs go; torch.autocast(bfloat16) on the reference's
+ * Linear / Conv2d is the closest reference-side equivalent).  The library keeps NO precision state: entry points are
+ * re-entrant and may be called with different precisions from different threads / streams. */
 
 /* ---- LePEAttention (cswin_unet.py:31-109), both branches of a CSWinBlock in one launch (:171-176) ----
  * qkv (B, L, 3C) = output of the qkv Linear, channel layout [q | k | v] (:169).
@@ -97,16 +96,16 @@ int cswin_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
  * x2 == NULL: single source.  row_scale may be NULL (= 1). */
 int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* w, const float* bias, float* y,
                      float* y_act, const float* residual, const float* row_scale, int rows_per_sample, int M, int N,
-                     int K, void* stream);
+                     int K, int precision, void* stream);
 /* dx (M, K) = add + row_scale * ((dy (M, N) @ w (N, K)) * gelu'(gelu_pre));  columns >= k_split go to dx2 if given */
 int cswin_linear_bwd_data(const float* dy, const float* w, float* dx, float* dx2, int k_split, const float* gelu_pre,
                           const float* row_scale, int rows_per_sample, const float* add, int M, int N, int K,
-                          void* stream);
+                          int precision, void* stream);
 size_t cswin_linear_bwd_weight_workspace(int M, int N, int K);
 /* dw (N, K) = (row_scale * dy)^T @ [x | x2];  dbias (N) = column sums (may be NULL); `deferred` as for layernorm_bwd */
 int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, int k_split, const float* row_scale,
                             int rows_per_sample, float* dw, float* dbias, void* workspace, size_t ws_bytes, int M,
-                            int N, int K, cswin_reduce_job* deferred, void* stream);
+                            int N, int K, cswin_reduce_job* deferred, int precision, void* stream);
 /* One problem of cswin_linear_bwd_weight_batch: dw (N, K) = (row_scale * dy)^T @ x, dbias (N) = column sums of dy (or NULL). */
 typedef struct cswin_wgrad_desc {
     const float* dy;         /* (M, N) */
@@ -116,7 +115,8 @@ typedef struct cswin_wgrad_desc {
     float* dbias;            /* (N) or NULL */
     void* workspace;         /* cswin_linear_bwd_weight_workspace(M, N, K) bytes */
     size_t ws_bytes;
-    int rows_per_sample, M, N, K, reserved;
+    int rows_per_sample, M, N, K;
+    int precision;           /* 0 = exact fp32 MFMA, 1 = bf16 operands (all problems of one launch agree) */
 } cswin_wgrad_desc;
 /* Up to 4 independent weight gradients (the four nn.Linear of a CSWinBlock, cswin_unet.py:125,134,17-19) in ONE launch;
  * deferred[0..n) receive their slab reductions (required: run them with cswin_rows_sum_multi). */
@@ -129,15 +129,15 @@ int cswin_rows_sum_multi(const cswin_reduce_job* jobs, int njobs, void* stream);
  * x (B, H*W, Cin) -> y (B, OH*OW, Cout).  Weights are given in the implicit-GEMM images made by
  * cswin_conv_weight_permute from the nn.Conv2d parameter [Cout][Cin][ks][ks]. Cin % 4 == 0. */
 int cswin_conv_tok_fwd(const float* x, const float* w_perm, const float* bias, float* y, int B, int H, int W, int Cin,
-                       int Cout, int ks, int stride, int pad, void* stream);
+                       int Cout, int ks, int stride, int pad, int precision, void* stream);
 int cswin_conv_tok_bwd_data(const float* dy, const float* w_permT, float* dx, int B, int H, int W, int Cin, int Cout,
-                            int ks, int stride, int pad, void* stream);
+                            int ks, int stride, int pad, int precision, void* stream);
 size_t cswin_conv_tok_bwd_weight_workspace(int B, int H, int W, int Cin, int Cout, int ks, int stride, int pad);
 /* dw: [Cout][ks*ks][Cin] (torch_layout 0, the image cswin_conv_weight_unpermute takes) or directly the nn.Conv2d parameter
  * layout [Cout][Cin][ks][ks] (torch_layout 1: the slab reduction writes it, no separate unpermute launch) */
 int cswin_conv_tok_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, void* workspace,
                               size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ks, int stride, int pad,
-                              int torch_layout, void* stream);
+                              int torch_layout, int precision, void* stream);
 /* w [Cout][Cin][ks][ks] -> w_perm [Cout][ks*ks][Cpad] and/or w_permT [ks*ks][Cout][Cpad] (zero padded channels) */
 int cswin_conv_weight_permute(const float* w, float* w_perm, float* w_permT, int Cout, int Cin, int ks, int Cpad,
                               void* stream);

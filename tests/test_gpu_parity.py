@@ -959,7 +959,7 @@ def test_linear_weight_gradient_batch_bf16(bf16_matmul, shapes):
         keep += [dyd, xd, rsd, ws]
         wg[i].dy, wg[i].x, wg[i].row_scale = dyd.data_ptr(), xd.data_ptr(), (rsd.data_ptr() if rsd is not None else None)
         wg[i].dw, wg[i].dbias, wg[i].workspace, wg[i].ws_bytes = dw.data_ptr(), (db.data_ptr() if with_bias else None), ws.data_ptr(), nbytes
-        wg[i].rows_per_sample, wg[i].M, wg[i].N, wg[i].K = rps, M, N_, K
+        wg[i].rows_per_sample, wg[i].M, wg[i].N, wg[i].K, wg[i].precision = rps, M, N_, K, 1
         scale = np.ones((M, 1), np.float32) if rs is None else np.array([rs[m // rps] for m in range(M)], np.float32)[:, None]
         dys = torch.from_numpy(dy * scale)
         xt = torch.from_numpy(x)

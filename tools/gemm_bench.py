@@ -4,7 +4,7 @@ into a hipGraph and replayed, so host launch overhead is excluded.  CSWIN_GEMM_T
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cswin_unet_amd._lib import call, lib, ptr, stream
+from cswin_unet_amd._lib import call, lib, ptr, stream, precision
 
 def timed(fn, reps=20, rounds=5):
     fn(); torch.cuda.synchronize()
@@ -35,9 +35,9 @@ for name, M, N, K in shapes:
     dw = torch.empty(N, K, device="cuda"); db = torch.empty(N, device="cuda")
     nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
     ws = torch.empty(nbytes // 4 + 4, device="cuda")
-    tf = timed(lambda: call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, stream()))
-    tdx = timed(lambda: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, stream()))
-    tdw = timed(lambda: call("cswin_linear_bwd_weight", ptr(dy), ptr(x), None, 0, None, 1, ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, None, stream()))
+    tf = timed(lambda: call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, precision(), stream()))
+    tdx = timed(lambda: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, precision(), stream()))
+    tdw = timed(lambda: call("cswin_linear_bwd_weight", ptr(dy), ptr(x), None, 0, None, 1, ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, None, precision(), stream()))
     fl = 2.0 * M * N * K
     c = counts[name[:2]]
     tot["fwd"] += c * tf; tot["dx"] += c * tdx; tot["dw"] += c * tdw; flops += 3 * c * fl

@@ -3,7 +3,7 @@
 import os, sys, ctypes
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cswin_unet_amd._lib import call, lib, ptr, stream
+from cswin_unet_amd._lib import call, lib, ptr, stream, precision
 M, N, K = (int(a) for a in sys.argv[1:4]); mode = sys.argv[4]
 x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda"); b = torch.randn(N, device="cuda")
 dy = torch.randn(M, N, device="cuda"); y = torch.empty(M, N, device="cuda"); dx = torch.empty(M, K, device="cuda")
@@ -14,9 +14,9 @@ dw = torch.empty(N, K, device="cuda"); db = torch.empty(N, device="cuda")
 nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K); ws = torch.empty(nbytes // 4 + 4, device="cuda")
 h = lib(); h.cswin_debug_set_stamps.argtypes = [ctypes.c_void_p]
 def run():
-    if mode == "fwd": call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, stream())
-    elif mode == "dw": call("cswin_linear_bwd_weight", ptr(dy), ptr(x), None, 0, None, 1, ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, None, stream())
-    else: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, stream())
+    if mode == "fwd": call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, precision(), stream())
+    elif mode == "dw": call("cswin_linear_bwd_weight", ptr(dy), ptr(x), None, 0, None, 1, ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, None, precision(), stream())
+    else: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, precision(), stream())
 for _ in range(3): run()
 torch.cuda.synchronize()
 h.cswin_debug_set_stamps(ctypes.c_void_p(st.data_ptr()))
