@@ -79,7 +79,6 @@ def attention_roofline(batch, cfg, img_size=224):
         b = [(torch.randn(cb, generator=g) * 0.02).to(dev) for _ in idx]
         dy = torch.randn(batch, L, C, generator=g).to(dev)
         y = torch.empty(batch, L, C, device=dev)
-        y0 = torch.empty(batch, L, C, device=dev) if n_tok <= 112 else None      # what ops.py passes (fused-backward windows)
         lse = torch.empty(batch, sum(hb), L, device=dev)
         dqkv = torch.empty_like(qkv)
         dw, db = [torch.empty_like(t) for t in w], [torch.empty_like(t) for t in b]
@@ -87,14 +86,13 @@ def attention_roofline(batch, cfg, img_size=224):
         pa = lambda ts: (ctypes.c_void_p * nb)(*[t.data_ptr() for t in ts])
         nbytes = lib().cswin_attn_bwd_workspace(batch, reso, C, nb, ha, ia, split[si])
         ws = torch.empty(nbytes // 4 + 4, device=dev)
-        t_f = _graph_time(lambda: call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(y0), ptr(lse), batch, reso, C, nb, ha, ia,
+        t_f = _graph_time(lambda: call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(lse), batch, reso, C, nb, ha, ia,
                                        split[si], 0.0, stream()))
-        t_b = _graph_time(lambda: call("cswin_attn_bwd", ptr(qkv), pa(w), pa(b), ptr(lse), ptr(y), ptr(y0), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws),
+        t_b = _graph_time(lambda: call("cswin_attn_bwd", ptr(qkv), pa(w), pa(b), ptr(lse), ptr(y), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws),
                                        nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, None, stream()))
         flops_f = 4.0 * L * n_tok * C * batch
         n_blocks = 2 * depth[si]
-        # fwd: q, k, v in, y (+ y0) out; bwd: q, k, v, dy, y0 in, dq, dk, dv out (y0 replaces y as the saved forward output)
-        bytes_f, bytes_b = (20.0 if y0 is not None else 16.0) * L * C * batch, 28.0 * L * C * batch
+        bytes_f, bytes_b = 16.0 * L * C * batch, 28.0 * L * C * batch
         rows.append({"stage": si + 1, "window_tokens": n_tok, "launches_per_step": n_blocks,
                      "fwd_us": round(t_f * 1e6, 2), "bwd_us": round(t_b * 1e6, 2),
                      "fwd_tflops": round(flops_f / t_f / 1e12, 2), "bwd_tflops": round(2 * flops_f / t_b / 1e12, 2),

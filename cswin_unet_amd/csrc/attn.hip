@@ -25,7 +25,6 @@
 // Head dims 8 / 16 / 24 / 32 share the kernels (tiles zero-padded to HD = 32).
 #include "common.h"
 #include <stdlib.h>
-#include <mutex>
 
 namespace {
 
@@ -47,8 +46,6 @@ struct AttnBranch {
 struct AttnParams {
     const float* qkv;      // (B, L, 3C)
     float* y;              // (B, L, C)        forward output
-    float* y0;             // (B, L, C)        forward: P V without the LePE term (optional; lets backward form delta without LePE)
-    const float* y0_in;    // (B, L, C)        backward: that tensor
     float* lse;            // (B, heads_total, L)
     const float* dy;       // (B, L, C)        backward input
     const float* y_in;     // (B, L, C)        forward output (large-window backward only: delta = rowsum(dO o (y - lepe)))
@@ -311,12 +308,8 @@ __global__ __launch_bounds__(64 * (QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8))) 
                 const int d0 = 16 * df + 4 * kq;
                 f32x4 acc = *reinterpret_cast<const f32x4*>(&Wl[9 * HD + d0]);     // bias
                 acc = thin ? lepe_taps4<true, 1>(br, Vs, Wl, rr, cc, tq, d0, acc) : lepe_taps4<false, 1>(br, Vs, Wl, rr, cc, tq, d0, acc);
-                const f32x4 pv = o[df] * inv;
-                f32x4 out = pv + acc;
-                if (d0 < p.hd) {
-                    *reinterpret_cast<f32x4*>(p.y + ((long)w.b * L + lq) * p.C + ch0 + d0) = out;
-                    if (p.y0) *reinterpret_cast<f32x4*>(p.y0 + ((long)w.b * L + lq) * p.C + ch0 + d0) = pv;
-                }
+                f32x4 out = o[df] * inv + acc;
+                if (d0 < p.hd) *reinterpret_cast<f32x4*>(p.y + ((long)w.b * L + lq) * p.C + ch0 + d0) = out;
             }
             if (kq == 0) p.lse[((long)w.b * p.heads_total + br.head0 + w.g) * L + lq] = mx + __logf(sum);
         }
@@ -344,10 +337,7 @@ __device__ __forceinline__ float oct_sum(float v) {
 //       are the B operands as they stand); dS -> LDS.  The S / dP products of tile qt + 1 are issued before the VALU
 //       work of tile qt.  Then dV += LePE^T(dO), dK, dV -> global.
 //   P3  K fragments -> LDS over the dead Q image; dQ^T = K^T dS^T per query tile (one per wave) -> global.
-// Y0 = true (the forward saved y0 = P V without LePE): delta[q] = sum_d dO[q][d] y0[q][d] is formed while P0 stages dO -- no
-// LePE recomputation, no V image, no P1 -- and the LePE weight / bias gradient is a separate streaming launch
-// (lepe_wgrad2_kernel), so this kernel is P0 -> P2 -> P3 only.
-template <int NT, bool Y0>
+template <int NT>
 __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {      // 4 waves per SIMD: <= 128 VGPRs, two workgroups per CU at NT = 7
     constexpr int NP = 16 * NT;
     constexpr int NTHREADS = 64 * NT;
@@ -356,7 +346,7 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
     float* QK = smem;                       // [NP][LDT]
     float* Ds = QK + NP * LDT;              // [NP][LDT]
     float* VS = Ds + NP * LDT;              // V [NP][LDT], then dS [NP][S]
-    constexpr int VS_MIN = Y0 ? 0 : NP * LDT + NT * 10 * HD;   // V image + the waves' LePE gradient slabs (P1)
+    constexpr int VS_MIN = NP * LDT + NT * 10 * HD;   // V image + the waves' LePE gradient slabs (P1)
     float* lse_s = VS + (NP * S > VS_MIN ? NP * S : VS_MIN);
     float* del_s = lse_s + NP;
     float* Wl = del_s + NP;                 // [10][HD]
@@ -370,7 +360,7 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
     const int N = w.N;
     const float* qkv_b = p.qkv + (long)w.b * L * C3;
     const float* dy_b = p.dy + (long)w.b * L * p.C;
-    const float* y_b = (Y0 ? p.y0_in : p.y_in) + (long)w.b * L * p.C;
+    const float* y_b = p.y_in + (long)w.b * L * p.C;
     float* dqkv_b = p.dqkv + (long)w.b * L * C3;
     const float* lse_b = p.lse + ((long)w.b * p.heads_total + br.head0 + w.g) * L;
     const bool thin = br.H_sp == 1 || br.W_sp == 1;       // wave-uniform
@@ -381,203 +371,158 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
     const int tk = 16 * kw + li;                       // this lane's key token
     const bool kvalid = tk < N;
     const int lk = kvalid ? token_of(br, w, p.reso, tk) : 0;
-    float kf[8], vf[8];
-    float lepe_part[2] = {0.f, 0.f};                    // (Y0 = false) elements tid, tid + NTHREADS of the workgroup's [10][HD] partial
-    if constexpr (Y0) {
-        f32x4 qv[2], dv[2], yv[2];
+    f32x4 qv[2], vv[2], dv[2];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = tid + it * NTHREADS, row = idx >> 3, c4 = idx & 7;
-            qv[it] = dv[it] = yv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (row < N && 4 * c4 < p.hd) {
-                const int l = token_of(br, w, p.reso, row);
-                qv[it] = *reinterpret_cast<const f32x4*>(qkv_b + (long)l * C3 + ch0 + 4 * c4);
-                dv[it] = *reinterpret_cast<const f32x4*>(dy_b + (long)l * p.C + ch0 + 4 * c4);
-                yv[it] = *reinterpret_cast<const f32x4*>(y_b + (long)l * p.C + ch0 + 4 * c4);
-            }
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * NTHREADS, row = idx >> 3, c4 = idx & 7;
+        qv[it] = vv[it] = dv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < N && 4 * c4 < p.hd) {
+            const int l = token_of(br, w, p.reso, row);
+            const float* src = qkv_b + (long)l * C3 + ch0 + 4 * c4;
+            qv[it] = *reinterpret_cast<const f32x4*>(src);
+            vv[it] = *reinterpret_cast<const f32x4*>(src + 2 * p.C);
+            dv[it] = *reinterpret_cast<const f32x4*>(dy_b + (long)l * p.C + ch0 + 4 * c4);
         }
-        {   // K / V fragments of this wave's 16 keys (B operands of P2), straight from global memory
-            f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, v0 = k0, v1 = k0;
-            if (kvalid && 8 * kq < p.hd) {
-                const float* src = qkv_b + (long)lk * C3 + ch0 + 8 * kq;
-                k0 = *reinterpret_cast<const f32x4*>(src + p.C);
-                k1 = *reinterpret_cast<const f32x4*>(src + p.C + 4);
-                v0 = *reinterpret_cast<const f32x4*>(src + 2 * p.C);
-                v1 = *reinterpret_cast<const f32x4*>(src + 2 * p.C + 4);
-            }
+    }
+    // P1 walks tokens t = 8 wave + (lane >> 3) + 8 NT j, j = 0, 1 (eight lanes per token, lane & 7 = 16-B channel chunk): its
+    // y values, loaded now
+    const int pc4 = lane & 7, ptg = lane >> 3;
+    f32x4 yv[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { kf[e] = k0[e]; kf[4 + e] = k1[e]; vf[e] = v0[e]; vf[4 + e] = v1[e]; }
-        }
-        for (int t = tid; t < NP; t += NTHREADS) lse_s[t] = t < N ? lse_b[token_of(br, w, p.reso, t)] : INFINITY;   // +inf -> P = 0 on padded query rows
-        for (int i = tid; i < 10 * HD; i += NTHREADS) {
-            const int tap = i / HD, ch = i - tap * HD;
-            const int cb = ch0 - br.c0 + ch;
-            Wl[i] = ch >= p.hd ? 0.f : (tap < 9 ? br.lepe_w[cb * 9 + tap] : br.lepe_b[cb]);
-        }
+    for (int j = 0; j < 2; ++j) {
+        const int t = 8 * wave + ptg + 8 * NT * j;
+        yv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < N && 4 * pc4 < p.hd) yv[j] = *reinterpret_cast<const f32x4*>(y_b + (long)token_of(br, w, p.reso, t) * p.C + ch0 + 4 * pc4);
+    }
+    for (int t = tid; t < NP; t += NTHREADS) {
+        lse_s[t] = t < N ? lse_b[token_of(br, w, p.reso, t)] : INFINITY;   // +inf -> P = 0 on padded query rows
+        del_s[t] = 0.f;
+    }
+    for (int i = tid; i < 10 * HD; i += NTHREADS) {
+        const int tap = i / HD, ch = i - tap * HD;
+        const int cb = ch0 - br.c0 + ch;
+        Wl[i] = ch >= p.hd ? 0.f : (tap < 9 ? br.lepe_w[cb * 9 + tap] : br.lepe_b[cb]);
+    }
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = tid + it * NTHREADS, row = idx >> 3, c4 = idx & 7;
-            *reinterpret_cast<f32x4*>(&QK[row * LDT + 4 * c4]) = qv[it];
-            *reinterpret_cast<f32x4*>(&Ds[row * LDT + 4 * c4]) = dv[it];
-            // delta[row] = sum_d dO y0 over the row's eight 16-B chunks (eight consecutive lanes); zero on padded rows
-            const float part = oct_sum(dv[it][0] * yv[it][0] + dv[it][1] * yv[it][1] + dv[it][2] * yv[it][2] + dv[it][3] * yv[it][3]);
-            if (c4 == 0) del_s[row] = part;
-        }
-        ATTN_STAMP(1);
-        ATTN_STAMP(2);
-        __syncthreads();
-    } else {
-        f32x4 qv[2], vv[2], dv[2];
-    #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = tid + it * NTHREADS, row = idx >> 3, c4 = idx & 7;
-            qv[it] = vv[it] = dv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (row < N && 4 * c4 < p.hd) {
-                const int l = token_of(br, w, p.reso, row);
-                const float* src = qkv_b + (long)l * C3 + ch0 + 4 * c4;
-                qv[it] = *reinterpret_cast<const f32x4*>(src);
-                vv[it] = *reinterpret_cast<const f32x4*>(src + 2 * p.C);
-                dv[it] = *reinterpret_cast<const f32x4*>(dy_b + (long)l * p.C + ch0 + 4 * c4);
-            }
-        }
-        // P1 walks tokens t = 8 wave + (lane >> 3) + 8 NT j, j = 0, 1 (eight lanes per token, lane & 7 = 16-B channel chunk): its
-        // y values, loaded now
-        const int pc4 = lane & 7, ptg = lane >> 3;
-        f32x4 yv[2];
-    #pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * NTHREADS, row = idx >> 3, c4 = idx & 7;
+        *reinterpret_cast<f32x4*>(&QK[row * LDT + 4 * c4]) = qv[it];
+        *reinterpret_cast<f32x4*>(&VS[row * LDT + 4 * c4]) = vv[it];
+        *reinterpret_cast<f32x4*>(&Ds[row * LDT + 4 * c4]) = dv[it];
+    }
+    __syncthreads();
+    ATTN_STAMP(1);
+
+    // ---- P1: per token: LePE weight-gradient terms, and delta = sum_d dO (y - bias - sum_tap W V_nbr) ----
+    // Eight lanes per token, four channels per lane: neighbour index and validity are computed once per 16 B instead of
+    // once per float, the taps are b128 LDS reads, delta is an 8-lane DPP sum.  The wave's [10][32] gradient partial goes
+    // to the part of the VS region that the V image does not use; it is combined over the waves after the barrier.
+    float* slab = VS + NP * LDT;                        // [NT][10][HD]
+    {
+        f32x4 a4[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) a4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 bias4 = *reinterpret_cast<const f32x4*>(&Wl[9 * HD + 4 * pc4]);
+#pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int t = 8 * wave + ptg + 8 * NT * j;
-            yv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (t < N && 4 * pc4 < p.hd) yv[j] = *reinterpret_cast<const f32x4*>(y_b + (long)token_of(br, w, p.reso, t) * p.C + ch0 + 4 * pc4);
-        }
-        for (int t = tid; t < NP; t += NTHREADS) {
-            lse_s[t] = t < N ? lse_b[token_of(br, w, p.reso, t)] : INFINITY;   // +inf -> P = 0 on padded query rows
-            del_s[t] = 0.f;
-        }
-        for (int i = tid; i < 10 * HD; i += NTHREADS) {
-            const int tap = i / HD, ch = i - tap * HD;
-            const int cb = ch0 - br.c0 + ch;
-            Wl[i] = ch >= p.hd ? 0.f : (tap < 9 ? br.lepe_w[cb * 9 + tap] : br.lepe_b[cb]);
-        }
-    #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = tid + it * NTHREADS, row = idx >> 3, c4 = idx & 7;
-            *reinterpret_cast<f32x4*>(&QK[row * LDT + 4 * c4]) = qv[it];
-            *reinterpret_cast<f32x4*>(&VS[row * LDT + 4 * c4]) = vv[it];
-            *reinterpret_cast<f32x4*>(&Ds[row * LDT + 4 * c4]) = dv[it];
-        }
-        __syncthreads();
-        ATTN_STAMP(1);
-
-        // ---- P1: per token: LePE weight-gradient terms, and delta = sum_d dO (y - bias - sum_tap W V_nbr) ----
-        // Eight lanes per token, four channels per lane: neighbour index and validity are computed once per 16 B instead of
-        // once per float, the taps are b128 LDS reads, delta is an 8-lane DPP sum.  The wave's [10][32] gradient partial goes
-        // to the part of the VS region that the V image does not use; it is combined over the waves after the barrier.
-        float* slab = VS + NP * LDT;                        // [NT][10][HD]
-        {
-            f32x4 a4[10];
-    #pragma unroll
-            for (int i = 0; i < 10; ++i) a4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const f32x4 bias4 = *reinterpret_cast<const f32x4*>(&Wl[9 * HD + 4 * pc4]);
-    #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int t = 8 * wave + ptg + 8 * NT * j;
-                const bool tv = t < N;
-                const int tc = tv ? t : 0;
-                f32x4 g4 = *reinterpret_cast<const f32x4*>(&Ds[tc * LDT + 4 * pc4]);
-                if (!tv) g4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                f32x4 lw4 = {0.f, 0.f, 0.f, 0.f};           // sum_tap W[tap] o V[nbr]
-                if (thin) {
-                    const bool row = br.H_sp == 1;
-    #pragma unroll
-                    for (int q = 0; q < 3; ++q) {           // a4[q] holds tap (1, q) or (q, 1); expanded below
-                        const int t2 = tc + q - 1;
-                        const bool ok = (unsigned)t2 < (unsigned)N;
-                        f32x4 v4 = *reinterpret_cast<const f32x4*>(&VS[(ok ? t2 : tc) * LDT + 4 * pc4]);
+            const bool tv = t < N;
+            const int tc = tv ? t : 0;
+            f32x4 g4 = *reinterpret_cast<const f32x4*>(&Ds[tc * LDT + 4 * pc4]);
+            if (!tv) g4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 lw4 = {0.f, 0.f, 0.f, 0.f};           // sum_tap W[tap] o V[nbr]
+            if (thin) {
+                const bool row = br.H_sp == 1;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {           // a4[q] holds tap (1, q) or (q, 1); expanded below
+                    const int t2 = tc + q - 1;
+                    const bool ok = (unsigned)t2 < (unsigned)N;
+                    f32x4 v4 = *reinterpret_cast<const f32x4*>(&VS[(ok ? t2 : tc) * LDT + 4 * pc4]);
+                    if (!ok) v4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&Wl[(row ? 3 + q : 3 * q + 1) * HD + 4 * pc4]);
+                    a4[q] += g4 * v4;
+                    lw4 += w4 * v4;
+                }
+            } else {
+                const int rr = tc / br.W_sp, cc = tc - rr * br.W_sp;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int r2 = rr + ky - 1, c2 = cc + kx - 1;
+                        const bool ok = (unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp;
+                        f32x4 v4 = *reinterpret_cast<const f32x4*>(&VS[(ok ? r2 * br.W_sp + c2 : tc) * LDT + 4 * pc4]);
                         if (!ok) v4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(&Wl[(row ? 3 + q : 3 * q + 1) * HD + 4 * pc4]);
-                        a4[q] += g4 * v4;
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(&Wl[(ky * 3 + kx) * HD + 4 * pc4]);
+                        a4[ky * 3 + kx] += g4 * v4;
                         lw4 += w4 * v4;
                     }
-                } else {
-                    const int rr = tc / br.W_sp, cc = tc - rr * br.W_sp;
-    #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-    #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const int r2 = rr + ky - 1, c2 = cc + kx - 1;
-                            const bool ok = (unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp;
-                            f32x4 v4 = *reinterpret_cast<const f32x4*>(&VS[(ok ? r2 * br.W_sp + c2 : tc) * LDT + 4 * pc4]);
-                            if (!ok) v4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(&Wl[(ky * 3 + kx) * HD + 4 * pc4]);
-                            a4[ky * 3 + kx] += g4 * v4;
-                            lw4 += w4 * v4;
-                        }
-                }
-                a4[9] += g4;
-                const f32x4 o4 = yv[j] - bias4 - lw4;
-                const float part = oct_sum(g4[0] * o4[0] + g4[1] * o4[1] + g4[2] * o4[2] + g4[3] * o4[3]);
-                if (tv && pc4 == 0) del_s[t] = part;
             }
-            if (thin) {                                             // a4[0..2] -> taps (1, q) or (q, 1); the other six are zero
-                const bool row = br.H_sp == 1;
-                const f32x4 t0 = a4[0], t1 = a4[1], t2 = a4[2], zero = {0.f, 0.f, 0.f, 0.f};
-                a4[0] = a4[2] = a4[6] = a4[8] = zero;
-                a4[1] = row ? zero : t0;
-                a4[3] = row ? t0 : zero;
-                a4[4] = t1;
-                a4[5] = row ? t2 : zero;
-                a4[7] = row ? zero : t2;
-            }
-            // sum over the eight token slots of the wave (lanes that share lane & 7): rotate by 8 inside the DPP row, then
-            // across the four rows
-    #pragma unroll
-            for (int i = 0; i < 10; ++i)
-    #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = a4[i][e];
-                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
-                    v += __shfl_xor(v, 16, 64);
-                    v += __shfl_xor(v, 32, 64);
-                    a4[i][e] = v;
-                }
-            if (lane < 8) {
-    #pragma unroll
-                for (int i = 0; i < 10; ++i) *reinterpret_cast<f32x4*>(&slab[(wave * 10 + i) * HD + 4 * lane]) = a4[i];
-            }
+            a4[9] += g4;
+            const f32x4 o4 = yv[j] - bias4 - lw4;
+            const float part = oct_sum(g4[0] * o4[0] + g4[1] * o4[1] + g4[2] * o4[2] + g4[3] * o4[3]);
+            if (tv && pc4 == 0) del_s[t] = part;
         }
-        // K / V fragments of this wave's 16 keys (B operands of P2): fetched only now, so that they do not sit in registers
-        // through P1 (whose accumulators would otherwise spill); the K load's latency hides behind the two barriers below
-        {
-            f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0;
-            if (kvalid && 8 * kq < p.hd) {
-                const float* src = qkv_b + (long)lk * C3 + p.C + ch0 + 8 * kq;
-                k0 = *reinterpret_cast<const f32x4*>(src);
-                k1 = *reinterpret_cast<const f32x4*>(src + 4);
-            }
-            const float* vp = &VS[tk * LDT + 8 * kq];
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp), v1 = *reinterpret_cast<const f32x4*>(vp + 4);
-    #pragma unroll
+        if (thin) {                                             // a4[0..2] -> taps (1, q) or (q, 1); the other six are zero
+            const bool row = br.H_sp == 1;
+            const f32x4 t0 = a4[0], t1 = a4[1], t2 = a4[2], zero = {0.f, 0.f, 0.f, 0.f};
+            a4[0] = a4[2] = a4[6] = a4[8] = zero;
+            a4[1] = row ? zero : t0;
+            a4[3] = row ? t0 : zero;
+            a4[4] = t1;
+            a4[5] = row ? t2 : zero;
+            a4[7] = row ? zero : t2;
+        }
+        // sum over the eight token slots of the wave (lanes that share lane & 7): rotate by 8 inside the DPP row, then
+        // across the four rows
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+#pragma unroll
             for (int e = 0; e < 4; ++e) {
-                kf[e] = k0[e];
-                kf[4 + e] = k1[e];
-                vf[e] = v0[e];
-                vf[4 + e] = v1[e];
+                float v = a4[i][e];
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                a4[i][e] = v;
             }
+        if (lane < 8) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) *reinterpret_cast<f32x4*>(&slab[(wave * 10 + i) * HD + 4 * lane]) = a4[i];
         }
-        ATTN_STAMP(2);
-        __syncthreads();                                    // V image dead; delta and the waves' LePE partials complete
-    #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = tid + u * NTHREADS;
-            if (i < 10 * HD) {
-    #pragma unroll
-                for (int k = 0; k < NT; ++k) lepe_part[u] += slab[k * 10 * HD + i];
-            }
-        }
-        __syncthreads();                                    // VS becomes the dS image
-
     }
+    // K / V fragments of this wave's 16 keys (B operands of P2): fetched only now, so that they do not sit in registers
+    // through P1 (whose accumulators would otherwise spill); the K load's latency hides behind the two barriers below
+    float kf[8], vf[8];
+    {
+        f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0;
+        if (kvalid && 8 * kq < p.hd) {
+            const float* src = qkv_b + (long)lk * C3 + p.C + ch0 + 8 * kq;
+            k0 = *reinterpret_cast<const f32x4*>(src);
+            k1 = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+        const float* vp = &VS[tk * LDT + 8 * kq];
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp), v1 = *reinterpret_cast<const f32x4*>(vp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            kf[e] = k0[e];
+            kf[4 + e] = k1[e];
+            vf[e] = v0[e];
+            vf[4 + e] = v1[e];
+        }
+    }
+    ATTN_STAMP(2);
+    __syncthreads();                                    // V image dead; delta and the waves' LePE partials complete
+    float lepe_part[2] = {0.f, 0.f};                    // elements tid, tid + NTHREADS of the workgroup's [10][HD] partial
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + u * NTHREADS;
+        if (i < 10 * HD) {
+#pragma unroll
+            for (int k = 0; k < NT; ++k) lepe_part[u] += slab[k * 10 * HD + i];
+        }
+    }
+    __syncthreads();                                    // VS becomes the dS image
+
     // ---- P2: fused S / dP -> P, dS -> dV^T, dK^T ----
     f32x4 dVt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x4 dKt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -675,11 +620,9 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
         }
     }
     ATTN_STAMP(5);
-    if constexpr (!Y0) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-            if (tid + u * NTHREADS < 10 * HD) store_lepe_partial(p, br, w, 0, tid + u * NTHREADS, lepe_part[u]);
-    }
+    for (int u = 0; u < 2; ++u)
+        if (tid + u * NTHREADS < 10 * HD) store_lepe_partial(p, br, w, 0, tid + u * NTHREADS, lepe_part[u]);
     ATTN_STAMP(6);
 }
 
@@ -978,58 +921,6 @@ __global__ __launch_bounds__(256) void lepe_wgrad_kernel(AttnParams p) {
     }
 }
 
-// LePE conv weight / bias gradient partial slabs straight from global memory (the fused backward's Y0 path): one workgroup
-// per (branch, window, head), thread = (token slot, 16-B channel chunk); the nine neighbours are 16-B loads (L2 resident:
-// v is read nine times by its own window only), the 32 slots are summed by lane shuffles and one small LDS pass.
-__global__ __launch_bounds__(256) void lepe_wgrad2_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) float red[4][10 * HD];
-    const WgInfo w = decode_wg(p, blockIdx.x);
-    const AttnBranch& br = p.br[w.bi];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c4 = tid & 7, slot = tid >> 3;
-    const int L = p.reso * p.reso, C3 = 3 * p.C, N = w.N;
-    const int ch0 = br.c0 + w.g * p.hd;
-    const bool c_ok = 4 * c4 < p.hd;
-    const float* v_b = p.qkv + (long)w.b * L * C3 + 2 * p.C + ch0 + 4 * c4;
-    const float* dy_b = p.dy + (long)w.b * L * p.C + ch0 + 4 * c4;
-    f32x4 a4[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) a4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t = slot; t < N; t += 32) {
-        const int rr = t / br.W_sp, cc = t - rr * br.W_sp;
-        f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
-        if (c_ok) g4 = *reinterpret_cast<const f32x4*>(dy_b + (long)token_of(br, w, p.reso, t) * p.C);
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int r2 = rr + ky - 1, c2 = cc + kx - 1;
-                const bool ok = c_ok && (unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp;
-                f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
-                if (ok) v4 = *reinterpret_cast<const f32x4*>(v_b + (long)token_of(br, w, p.reso, r2 * br.W_sp + c2) * C3);
-                a4[ky * 3 + kx] += g4 * v4;
-            }
-        a4[9] += g4;
-    }
-    // lanes that share lane & 7 hold the same channels: sum the wave's eight token slots, then the four waves through LDS
-#pragma unroll
-    for (int i = 0; i < 10; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = a4[i][e];
-            v += __shfl_xor(v, 8, 64);
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            a4[i][e] = v;
-        }
-    if (lane < 8) {
-#pragma unroll
-        for (int i = 0; i < 10; ++i) *reinterpret_cast<f32x4*>(&red[wave][i * HD + 4 * lane]) = a4[i];
-    }
-    __syncthreads();
-    for (int i = tid; i < 10 * HD; i += 256) store_lepe_partial(p, br, w, 0, i, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
-}
-
 // =====================================================================================
 // standalone index-only window gather / scatter (img2windows / windows2img, cswin_unet.py:184-202)
 // =====================================================================================
@@ -1112,13 +1003,11 @@ template <int NT>
 int launch_fwd(const AttnParams& p, int nwg, hipStream_t st) {
     constexpr int NW = NT < 8 ? NT : 8;
     const size_t lds = (size_t)(2 * 16 * NT * LDT + 10 * HD) * sizeof(float);
-    if (lds > 64 * 1024) {
-        // dynamic-LDS opt-in of this instantiation: once per process, thread-safe, idempotent (a function attribute, not a
-        // stream operation: it stays out of graph captures); the size is a constant of the template
-        static std::once_flag once;
-        static hipError_t status = hipSuccess;
-        std::call_once(once, [&] { status = hipFuncSetAttribute((const void*)attn_fwd_kernel<NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-        if (status != hipSuccess) { cswin_set_error("attn_fwd: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(status)); return CSWIN_ERR_HIP; }
+    static bool reserved = false;       // one-time, idempotent: not a stream operation, keep it out of graph captures
+    if (lds > 64 * 1024 && !reserved) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { cswin_set_error("attn_fwd: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return CSWIN_ERR_HIP; }
+        reserved = true;
     }
     if constexpr (NT <= 8) {
         // few units relative to the 256 CUs: split the query tiles over two workgroups per unit (see the kernel)
@@ -1139,22 +1028,18 @@ inline int ds_stride_for(int N) {            // smallest stride >= N with stride
     return s;
 }
 
-template <int NT, bool Y0>
+template <int NT>
 int launch_bwd2(const AttnParams& p, int nwg, hipStream_t st) {
-    constexpr int NP = 16 * NT;
-    const int S = p.ds_stride;
-    const int vs_min = Y0 ? 0 : NP * LDT + NT * 10 * HD;
+    const int NP = 16 * NT, S = p.ds_stride;
+    const int vs_min = NP * LDT + NT * 10 * HD;
     const size_t lds = (size_t)(2 * NP * LDT + (NP * S > vs_min ? NP * S : vs_min) + 2 * NP + 10 * HD) * sizeof(float);
-    if (lds > 64 * 1024) {
-        // once per process and instantiation, thread-safe: reserve the largest footprint this NT can ask for (N = 16 NT tokens)
-        static std::once_flag once;
-        static hipError_t status = hipSuccess;
-        constexpr int SMAX = ((NP + 3) / 4 * 4) + 8;
-        constexpr size_t lds_max = (size_t)(2 * NP * LDT + NP * SMAX + 2 * NP + 10 * HD) * sizeof(float);
-        std::call_once(once, [&] { status = hipFuncSetAttribute((const void*)attn_bwd2_kernel<NT, Y0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); });
-        if (status != hipSuccess) { cswin_set_error("attn_bwd: cannot reserve %zu B LDS: %s", lds_max, hipGetErrorString(status)); return CSWIN_ERR_HIP; }
+    static size_t reserved = 0;         // one-time per size: not a stream operation, keep it out of graph captures
+    if (lds > 64 * 1024 && lds > reserved) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd2_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { cswin_set_error("attn_bwd: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return CSWIN_ERR_HIP; }
+        reserved = lds;
     }
-    hipLaunchKernelGGL((attn_bwd2_kernel<NT, Y0>), dim3(nwg), dim3(64 * NT), lds, st, p);
+    hipLaunchKernelGGL((attn_bwd2_kernel<NT>), dim3(nwg), dim3(64 * NT), lds, st, p);
     return CSWIN_OK;
 }
 
@@ -1169,7 +1054,7 @@ void cswin_debug_set_attn_stamps(void* p) { g_attn_stamps = (long long*)p; }
 
 // qkv (B, L, 3C) -> y (B, L, C), lse (B, heads_total, L).  nbranch = 2: branch i uses channels
 // [i*C/2, (i+1)*C/2) with stripe mode idx[i]; nbranch = 1: whole C, idx[0] (normally -1).
-int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, float* y, float* y0, float* lse,
+int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, float* y, float* lse,
                    int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split, float scale, void* stream) {
     AttnParams p = {};
     int nt, nwg;
@@ -1177,7 +1062,7 @@ int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* co
     if (rc) return rc;
     CSWIN_REQUIRE(qkv && y && lse && lepe_w && lepe_b, CSWIN_ERR_SHAPE, "attn_fwd: null pointer");
     for (int i = 0; i < nbranch; ++i) { p.br[i].lepe_w = lepe_w[i]; p.br[i].lepe_b = lepe_b[i]; }
-    p.qkv = qkv; p.y = y; p.y0 = y0; p.lse = lse;
+    p.qkv = qkv; p.y = y; p.lse = lse;
     p.stamps = g_attn_stamps;
     hipStream_t st = (hipStream_t)stream;
     switch (nt) {
@@ -1209,7 +1094,7 @@ size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* 
 
 // dqkv (B, L, 3C) is fully overwritten; dlepe_w[i] (Cb,9) and dlepe_b[i] (Cb) are overwritten.
 int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, const float* lse,
-                   const float* y, const float* y0, const float* dy, float* dqkv, float* const* dlepe_w, float* const* dlepe_b,
+                   const float* y, const float* dy, float* dqkv, float* const* dlepe_w, float* const* dlepe_b,
                    void* workspace, size_t ws_bytes, int B, int reso, int C, int nbranch, const int* heads, const int* idx,
                    int split, float scale, cswin_reduce_job* deferred, void* stream) {
     AttnParams p = {};
@@ -1218,12 +1103,9 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
     if (rc) return rc;
     CSWIN_REQUIRE(qkv && lse && dy && dqkv && lepe_w && dlepe_w && dlepe_b, CSWIN_ERR_SHAPE, "attn_bwd: null pointer");
     CSWIN_REQUIRE(workspace && ws_bytes >= cswin_attn_bwd_workspace(B, reso, C, nbranch, heads, idx, split), CSWIN_ERR_WORKSPACE, "attn_bwd: workspace too small");
-    CSWIN_REQUIRE((y || y0) && lepe_b, CSWIN_ERR_SHAPE, "attn_bwd: the forward output y (or y0) and lepe_b are required");
+    CSWIN_REQUIRE(y && lepe_b, CSWIN_ERR_SHAPE, "attn_bwd: the forward output y and lepe_b are required");
     static const bool force_two_pass = getenv("CSWIN_ATTN_BWD_TWO_PASS") != nullptr;     // tuning aid
     const bool two_pass = nt > 7 || force_two_pass;
-    CSWIN_REQUIRE(y || !two_pass, CSWIN_ERR_SHAPE, "attn_bwd: windows of more than 112 tokens need the forward output y");
-    static const bool no_y0 = getenv("CSWIN_ATTN_BWD_NO_Y0") != nullptr;                   // tuning aid: force the LePE-recomputing path
-    const bool use_y0 = y0 != nullptr && !two_pass && !(no_y0 && y);
     p.slab_rows = 1;
     p.ds_stride = ds_stride_for(p.br[0].H_sp * p.br[0].W_sp);
     for (int i = 0; i < nbranch; ++i) {
@@ -1233,7 +1115,6 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
     }
     p.stamps = g_attn_stamps;
     p.y_in = y;
-    p.y0_in = y0;
     p.delta = (float*)workspace + (size_t)nwg * 10 * HD;
     p.qkv = qkv; p.lse = const_cast<float*>(lse); p.dy = dy; p.dqkv = dqkv;
     hipStream_t st = (hipStream_t)stream;
@@ -1247,20 +1128,10 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
         hipLaunchKernelGGL(lepe_wgrad_kernel, dim3(nwg), dim3(256), 0, st, p);
         rc = CSWIN_OK;
     } else {
-        if (use_y0) {
-            hipLaunchKernelGGL(lepe_wgrad2_kernel, dim3(nwg), dim3(256), 0, st, p);
-            switch (nt) {
-                case 1: case 2: case 3: case 4: rc = launch_bwd2<4, true>(p, nwg, st); break;
-                case 5: case 6: rc = launch_bwd2<6, true>(p, nwg, st); break;
-                default: rc = launch_bwd2<7, true>(p, nwg, st); break;
-            }
-        } else {
-            CSWIN_REQUIRE(y, CSWIN_ERR_SHAPE, "attn_bwd: the forward output y is required");
-            switch (nt) {
-                case 1: case 2: case 3: case 4: rc = launch_bwd2<4, false>(p, nwg, st); break;
-                case 5: case 6: rc = launch_bwd2<6, false>(p, nwg, st); break;
-                default: rc = launch_bwd2<7, false>(p, nwg, st); break;
-            }
+        switch (nt) {
+            case 1: case 2: case 3: case 4: rc = launch_bwd2<4>(p, nwg, st); break;
+            case 5: case 6: rc = launch_bwd2<6>(p, nwg, st); break;
+            default: rc = launch_bwd2<7>(p, nwg, st); break;
         }
     }
     if (rc) return rc;

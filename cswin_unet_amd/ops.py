@@ -347,14 +347,6 @@ def matmul_nn(a, b):
 # ------------------------------------------------------------------------------------------------
 # fused stripe attention
 # ------------------------------------------------------------------------------------------------
-def _window_tokens(reso, split, idx):
-    return reso * reso if idx[0] == -1 else reso * split
-
-
-# windows of up to 112 tokens run the fused backward, which wants y0 = P V without the LePE term (delta = rowsum(dO o y0))
-_Y0_MAX_TOKENS = 112
-
-
 class _StripeAttention(Function):
     @staticmethod
     def forward(ctx, qkv, reso, split, idx, heads, scale, *wb):
@@ -367,12 +359,10 @@ class _StripeAttention(Function):
         if L != reso * reso:
             raise ValueError("flatten img_tokens has wrong size")
         y = torch.empty(B, L, C, dtype=torch.float32, device=qkv.device)
-        y0 = torch.empty_like(y) if _window_tokens(reso, split, idx) <= _Y0_MAX_TOKENS else None
         lse = torch.empty(B, sum(heads), L, dtype=torch.float32, device=qkv.device)
-        call("cswin_attn_fwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(y), ptr(y0), ptr(lse), B, reso, C, nb,
+        call("cswin_attn_fwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(y), ptr(lse), B, reso, C, nb,
              _int_array(heads), _int_array(idx), split, float(scale or 0.0), stream())
-        ctx.has_y0 = y0 is not None
-        ctx.save_for_backward(qkv, lse, y0 if y0 is not None else y, *ws_, *bs_)
+        ctx.save_for_backward(qkv, lse, y, *ws_, *bs_)
         ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0))
         return y
 
@@ -392,8 +382,7 @@ class _StripeAttention(Function):
         ha, ia = _int_array(heads), _int_array(idx)
         nbytes = lib().cswin_attn_bwd_workspace(B, reso, C, nb, ha, ia, split)
         ws = _ws(nbytes, qkv.device)
-        call("cswin_attn_bwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(lse), None if ctx.has_y0 else ptr(y),
-             ptr(y) if ctx.has_y0 else None, ptr(dy), ptr(dqkv), _ptr_array(dws),
+        call("cswin_attn_bwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(lse), ptr(y), ptr(dy), ptr(dqkv), _ptr_array(dws),
              _ptr_array(dbs), ptr(ws), nbytes, B, reso, C, nb, ha, ia, split, scale, None, stream())
         return (dqkv, None, None, None, None, None) + tuple(d.view(d.shape[0], 1, 3, 3) for d in dws) + tuple(dbs)
 
@@ -432,9 +421,8 @@ class _CSWinBlock(Function):
         qkv = E(B, L, 3 * C)
         call("cswin_linear_fwd", ptr(h1), None, 0, ptr(wqkv), ptr(bqkv), ptr(qkv), None, None, None, 1, M, 3 * C, C, precision(), st)
         att, lse = E(B, L, C), E(B, sum(heads), L)
-        y0 = E(B, L, C) if _window_tokens(reso, split, idx) <= _Y0_MAX_TOKENS else None
         ha, ia = _int_array(heads), _int_array(idx)
-        call("cswin_attn_fwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(att), ptr(y0), ptr(lse), B, reso, C, nb, ha, ia, split,
+        call("cswin_attn_fwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(att), ptr(lse), B, reso, C, nb, ha, ia, split,
              float(scale or 0.0), st)
         x1 = torch.empty_like(x)
         call("cswin_linear_fwd", ptr(att), None, 0, ptr(wp), ptr(bp), ptr(x1), None, ptr(x), ptr(rs1), L, M, C, C, precision(), st)
@@ -445,14 +433,14 @@ class _CSWinBlock(Function):
         call("cswin_linear_fwd", ptr(h2), None, 0, ptr(w1), ptr(bb1), ptr(pre), ptr(act), None, None, 1, M, Hd, C, precision(), st)
         y = torch.empty_like(x)
         call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(bb2), ptr(y), None, ptr(x1), ptr(rs2), L, M, C, Hd, precision(), st)
-        ctx.save_for_backward(x, m1, r1, h1, qkv, lse, att, y0, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lw, *lb)
+        ctx.save_for_backward(x, m1, r1, h1, qkv, lse, att, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lw, *lb)
         ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0), bqkv is not None)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        (x, m1, r1, h1, qkv, lse, att, y0, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lwb) = ctx.saved_tensors
+        (x, m1, r1, h1, qkv, lse, att, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lwb) = ctx.saved_tensors
         reso, split, idx, heads, scale, has_qkv_bias = ctx.meta
         lw, lb = lwb[:len(idx)], lwb[len(idx):]
         dy = dev_f32(dy)
@@ -512,7 +500,7 @@ class _CSWinBlock(Function):
         ha, ia = _int_array(heads), _int_array(idx)
         naw = h.cswin_attn_bwd_workspace(B, reso, C, nb, ha, ia, split)
         aws = _ws(naw, dev)
-        call("cswin_attn_bwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(lse), ptr(att), ptr(y0), ptr(datt), ptr(dqkv),
+        call("cswin_attn_bwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(lse), ptr(att), ptr(datt), ptr(dqkv),
              _ptr_array(dlw), _ptr_array(dlb), ptr(aws), naw, B, reso, C, nb, ha, ia, split, scale, J(6), st)
         dwqkv = torch.empty_like(wqkv)
         dbqkv = E(3 * C) if has_qkv_bias else None

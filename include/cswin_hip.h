@@ -60,19 +60,16 @@ int cswin_device_ok(void); /* 1 if the current HIP device is gfx950 */
  * lepe_w[i] (Cb, 9) / lepe_b[i] (Cb) = get_v depthwise 3x3 weight/bias of branch i (:55).
  * y (B, L, C): x = softmax(scale q k^T) v + lepe, scattered by windows2img and concatenated (:98-107, :174).
  * lse (B, sum(heads), L): row log-sum-exp saved for backward.  scale <= 0 selects head_dim^-0.5 (:42). */
-int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, float* y, float* y0, float* lse,
+int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, float* y, float* lse,
                    int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split, float scale,
                    void* stream);
 size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split);
-/* y0 (B, L, C) of cswin_attn_fwd: optional second output = softmax(QK^T) V WITHOUT the LePE term (y = y0 + LePE(v)); NULL = not written.
- * autograd backward of the above: dqkv (B, L, 3C), dlepe_w[i] (Cb, 9), dlepe_b[i] (Cb) are overwritten.
- * The softmax-backward row term delta[q] = rowsum(P o dP) = sum_d dO[q][d] y0[q][d]: with y0 given (windows of up to 112
- * tokens) the fused kernel forms it while staging dO, and the LePE weight / bias gradient is its own streaming launch;
- * without y0 it is recomputed from y - LePE(v) inside the kernel (y required then, and always for larger windows).
- * The per-window partial slabs of the LePE conv weight / bias gradient are reduced by one extra launch, or left in
- * deferred[0..nbranch) for cswin_rows_sum_multi. */
+/* autograd backward of the above: dqkv (B, L, 3C), dlepe_w[i] (Cb, 9), dlepe_b[i] (Cb) are overwritten.
+ * y (the forward output) and lepe_b are only read for windows of more than 112 tokens (384x384 inputs), where a
+ * two-pass path replaces the fused kernel; they may be NULL otherwise.  The per-window partial slabs of the LePE conv
+ * weight / bias gradient are reduced by one extra launch, or left in deferred[0..nbranch) for cswin_rows_sum_multi. */
 int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, const float* lse,
-                   const float* y, const float* y0, const float* dy, float* dqkv, float* const* dlepe_w, float* const* dlepe_b,
+                   const float* y, const float* dy, float* dqkv, float* const* dlepe_w, float* const* dlepe_b,
                    void* workspace, size_t ws_bytes, int B, int reso, int C, int nbranch, const int* heads, const int* idx,
                    int split, float scale, cswin_reduce_job* deferred, void* stream);
 
