@@ -25,6 +25,7 @@
 // Head dims 8 / 16 / 24 / 32 share the kernels (tiles zero-padded to HD = 32).
 #include "common.h"
 #include <stdlib.h>
+#include <mutex>
 
 namespace {
 
@@ -1003,11 +1004,13 @@ template <int NT>
 int launch_fwd(const AttnParams& p, int nwg, hipStream_t st) {
     constexpr int NW = NT < 8 ? NT : 8;
     const size_t lds = (size_t)(2 * 16 * NT * LDT + 10 * HD) * sizeof(float);
-    static bool reserved = false;       // one-time, idempotent: not a stream operation, keep it out of graph captures
-    if (lds > 64 * 1024 && !reserved) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { cswin_set_error("attn_fwd: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return CSWIN_ERR_HIP; }
-        reserved = true;
+    if (lds > 64 * 1024) {
+        // dynamic-LDS opt-in of this instantiation: once per process, thread-safe, idempotent (a function attribute, not a
+        // stream operation: it stays out of graph captures); the size is a constant of the template
+        static std::once_flag once;
+        static hipError_t status = hipSuccess;
+        std::call_once(once, [&] { status = hipFuncSetAttribute((const void*)attn_fwd_kernel<NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+        if (status != hipSuccess) { cswin_set_error("attn_fwd: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(status)); return CSWIN_ERR_HIP; }
     }
     if constexpr (NT <= 8) {
         // few units relative to the 256 CUs: split the query tiles over two workgroups per unit (see the kernel)
@@ -1030,14 +1033,18 @@ inline int ds_stride_for(int N) {            // smallest stride >= N with stride
 
 template <int NT>
 int launch_bwd2(const AttnParams& p, int nwg, hipStream_t st) {
-    const int NP = 16 * NT, S = p.ds_stride;
+    constexpr int NP = 16 * NT;
+    const int S = p.ds_stride;
     const int vs_min = NP * LDT + NT * 10 * HD;
     const size_t lds = (size_t)(2 * NP * LDT + (NP * S > vs_min ? NP * S : vs_min) + 2 * NP + 10 * HD) * sizeof(float);
-    static size_t reserved = 0;         // one-time per size: not a stream operation, keep it out of graph captures
-    if (lds > 64 * 1024 && lds > reserved) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd2_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { cswin_set_error("attn_bwd: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return CSWIN_ERR_HIP; }
-        reserved = lds;
+    if (lds > 64 * 1024) {
+        // once per process and instantiation, thread-safe: reserve the largest footprint this NT can ask for (N = 16 NT tokens)
+        static std::once_flag once;
+        static hipError_t status = hipSuccess;
+        constexpr int SMAX = ((NP + 3) / 4 * 4) + 8;
+        constexpr size_t lds_max = (size_t)(2 * NP * LDT + NP * SMAX + 2 * NP + 10 * HD) * sizeof(float);
+        std::call_once(once, [&] { status = hipFuncSetAttribute((const void*)attn_bwd2_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); });
+        if (status != hipSuccess) { cswin_set_error("attn_bwd: cannot reserve %zu B LDS: %s", lds_max, hipGetErrorString(status)); return CSWIN_ERR_HIP; }
     }
     hipLaunchKernelGGL((attn_bwd2_kernel<NT>), dim3(nwg), dim3(64 * NT), lds, st, p);
     return CSWIN_OK;

@@ -21,6 +21,7 @@
 // Activation staging drops to 2-4 B per cycle and CU, the weight is read once per CU, and the MFMA stream of a wave is
 // 32 back-to-back instructions per step between two barriers.
 #include <stdlib.h>
+#include <mutex>
 
 #include "gemm_epilogue.h"
 
@@ -335,12 +336,10 @@ template <int KS, int NWN, int NWK, bool BTRANS, int EPI>
 int ws_launch(const WsParams& p, hipStream_t st) {
     constexpr size_t lds = ws_lds_bytes<KS, NWN, NWK>();
     auto kern = ws_gemm_kernel<KS, NWN, NWK, BTRANS, EPI>;
-    static bool reserved = false;       // one-time, idempotent (not a stream operation: stays out of graph captures)
-    if (!reserved) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { cswin_set_error("ws_gemm: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return CSWIN_ERR_HIP; }
-        reserved = true;
-    }
+    static std::once_flag once;         // once per process and instantiation, thread-safe (a function attribute, not a stream operation)
+    static hipError_t status = hipSuccess;
+    std::call_once(once, [&] { status = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    if (status != hipSuccess) { cswin_set_error("ws_gemm: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(status)); return CSWIN_ERR_HIP; }
     hipLaunchKernelGGL(kern, dim3(p.n_groups * p.slots), dim3(64 * NWN * NWK), lds, st, p);
     return CSWIN_OK;
 }
