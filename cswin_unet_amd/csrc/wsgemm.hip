@@ -22,6 +22,7 @@
 // 32 back-to-back instructions per step between two barriers.
 #include <stdlib.h>
 #include <mutex>
+#include <type_traits>
 
 #include "gemm_epilogue.h"
 
@@ -172,32 +173,6 @@ __global__ __launch_bounds__(64 * NWN * NWK, 2) void ws_gemm_kernel(WsParams p) 
     const bool active = ncol0 < p.N;                       // wave-uniform
 
     WS_STAMP(0);
-    // ---- the weight slice of this wave -> registers: breg[4 * (koff / 8) + s] = Bm(wk*KS + koff + 4 lh + s, ncol0 + li) ----
-    float breg[KS / 2];
-    {
-        const int n = ncol0 + li;
-        const bool nok = n < p.N;
-        if constexpr (!BTRANS) {
-            const float* wrow = p.W + (long)(nok ? n : 0) * p.ldw + wk * KS + 4 * lh;
-#pragma unroll
-            for (int g = 0; g < KS / 8; ++g) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(wrow + 8 * g);
-                if (!nok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 4; ++s) breg[4 * g + s] = v[s];
-            }
-        } else {
-            const float* wcol = p.W + (long)(wk * KS + 4 * lh) * p.ldw + (nok ? n : 0);
-#pragma unroll
-            for (int g = 0; g < KS / 8; ++g)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float v = wcol[(long)(8 * g + s) * p.ldw];
-                    breg[4 * g + s] = nok ? v : 0.f;
-                }
-        }
-    }
-
     // ---- LDS-DMA geometry: instruction q of this wave covers k-group gq, rows 8*rb .. +8 of the tile (8 lanes x 16 B per row) ----
     // lane -> (row = 8 rb + lane/8, physical chunk pc = lane & 7) holds logical chunk pc ^ ((row >> 1) & 7) of that row
     int q_row[Q];
@@ -233,20 +208,54 @@ __global__ __launch_bounds__(64 * NWN * NWK, 2) void ws_gemm_kernel(WsParams p) 
         return *reinterpret_cast<const f32x4*>(st + wk * WS_STAGE_FLOATS + (32 * hm + li) * WS_BK + 4 * pc);
     };
 
-    // bias of this wave's columns in the epilogue's lane layout (lane owns columns ncol0 + 4 (lane & 7) .. +3): loaded once
-    f32x4 bias_v = {0.f, 0.f, 0.f, 0.f};
-    {
-        const int n = ncol0 + (lane & 7) * 4;
-        if (p.epi.bias && n < p.N) bias_v = *reinterpret_cast<const f32x4*>(p.epi.bias + n);
-    }
+    // ---- prologue.  Issue order = vmcnt order: [DMA of steps 0 .. D-2] [NWL weight loads] [1 bias load].  The activations of
+    // the first steps are therefore NOT queued behind the 32 KB of weights of this wave, and the first tile (peeled below)
+    // starts its MFMAs as soon as step 0 and the first sixteen weight registers have landed: hipcc waits for its own loads
+    // register by register, and every load between the DMA and the first counted wait is unconditional, so their number
+    // is a constant the hand-written waits can add to their counts.
     if (total > 0) {
 #pragma unroll
         for (int s = 0; s < D - 1; ++s)
             if (s < total) issue(s);
     }
-    // Everything hipcc knows to be in flight (weight and bias loads) is retired HERE, so that its s_waitcnt pass has nothing
-    // pending at the loop header: otherwise it drains vmcnt(0) -- stores and LDS-DMA included -- at the top of every tile.
-    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): also covers the DMA of the first D - 1 stages
+    // every wave's DMA is in the CU's memory queue before any wave's weight loads (the texture path serves requests in arrival
+    // order: without this barrier the DMA of the last waves sit behind the 32-KB weight streams of the first)
+    ws_barrier();
+    constexpr int NWL = BTRANS ? KS / 2 : KS / 8;          // weight load instructions per lane
+    // the weight slice of this wave -> registers: breg[4 * (koff / 8) + s] = Bm(wk*KS + koff + 4 lh + s, ncol0 + li)
+    float breg[KS / 2];
+    {
+        // columns past N (last n-group) re-read column N - 1: their products are never stored.  No select on the loaded
+        // values: it would make hipcc wait for every weight load right here instead of at the MFMA that first uses it.
+        const int n = min(ncol0 + li, p.N - 1);
+        if constexpr (!BTRANS) {
+            const float* wrow = p.W + (long)n * p.ldw + wk * KS + 4 * lh;
+#pragma unroll
+            for (int g = 0; g < KS / 8; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + 8 * g);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) breg[4 * g + s] = v[s];
+            }
+        } else {
+            const float* wcol = p.W + (long)(wk * KS + 4 * lh) * p.ldw + n;
+#pragma unroll
+            for (int g = 0; g < KS / 8; ++g)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) breg[4 * g + s] = wcol[(long)(8 * g + s) * p.ldw];
+        }
+    }
+    // bias of this wave's columns in the epilogue's lane layout (lane owns columns ncol0 + 4 (lane & 7) .. +3): loaded once,
+    // unconditionally (from the weight matrix when there is no bias: the value is then discarded)
+    f32x4 bias_raw;
+    bool has_bias;
+    {
+        const int n = ncol0 + (lane & 7) * 4;
+        has_bias = p.epi.bias && n < p.N;
+        bias_raw = *reinterpret_cast<const f32x4*>(has_bias ? p.epi.bias + n : p.W);     // selected where it is used (epilogue)
+    }
+    constexpr int N_PRO = (D - 2) * Q + NWL + 1 > 63 ? 63 : (D - 2) * Q + NWL + 1;     // vmcnt is a 6-bit field
+    if (total > D - 2) ws_wait_vmcnt<N_PRO>();             // my DMA of step 0 has landed (everything younger may be in flight)
+    else ws_wait_vmcnt<0>();
     WS_STAMP(1);
     ws_barrier();                                          // step 0 has landed for every wave
     WS_STAMP(2);
@@ -254,9 +263,11 @@ __global__ __launch_bounds__(64 * NWN * NWK, 2) void ws_gemm_kernel(WsParams p) 
     // Step protocol (one barrier per step): issue the DMA of step s + D - 1 into the stage that step s - 1 just released ->
     // MFMAs of step s -> wait for MY DMA of step s + 1 (counted: the later stages stay in flight) -> [tile end: epilogue]
     // -> barrier.  The wait sits BEFORE the epilogue's stores: vmcnt retires in issue order, so a counted wait behind
-    // freshly issued stores would wait for them too.
+    // freshly issued stores would wait for them too.  FIRST (the peeled first tile): the weight loads are still in the queue
+    // behind the prologue's DMA, so waits for steps 1 .. D-2 allow N_PRO operations in flight.
     int s = 0;
-    for (int tile = 0; tile < ntiles; ++tile) {
+    auto run_tile = [&](auto first_tag, int tile) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         const bool full = 2 * tile + 1 < n_units;          // second 32-row block belongs to this workgroup
         f32x16 acc[2][1];
         WsEpiRegs<EPI> er;
@@ -289,8 +300,9 @@ __global__ __launch_bounds__(64 * NWN * NWK, 2) void ws_gemm_kernel(WsParams p) 
             // my DMA of step s + 1 has landed once at most the (D - 2) later stages are outstanding.  The tile's last step
             // retires everything instead (the epilogue operands just loaded sit behind the DMA in the in-order counter).
             if (kc == NKC - 1) __builtin_amdgcn_s_waitcnt(0x0F70);
-            else if (s + D - 1 < total) ws_wait_vmcnt<(D - 2) * Q>();
-            else ws_wait_vmcnt<0>();
+            else if (s + D - 1 >= total) ws_wait_vmcnt<0>();
+            else if (FIRST && kc + 1 <= D - 2) ws_wait_vmcnt<N_PRO>();      // step kc + 1 was issued in the prologue, ahead of the weights
+            else ws_wait_vmcnt<(D - 2) * Q>();
             if (kc + 1 < NKC) ws_barrier();                // (the tile's last barrier comes after the epilogue)
         }
         WS_STAMP(3 + 2 * tile);
@@ -317,10 +329,12 @@ __global__ __launch_bounds__(64 * NWN * NWK, 2) void ws_gemm_kernel(WsParams p) 
             }
         }
         if (wk == 0 && active)
-            ws_epi_store<EPI>(er, p.epi, acc, bias_v, row_end, p.N, row_base + tile * WS_BM, ncol0, lane, scratch + wave * EP_WAVE_FLOATS, full);
+            ws_epi_store<EPI>(er, p.epi, acc, has_bias ? bias_raw : f32x4{0.f, 0.f, 0.f, 0.f}, row_end, p.N, row_base + tile * WS_BM, ncol0, lane, scratch + wave * EP_WAVE_FLOATS, full);
         WS_STAMP(4 + 2 * tile);
         ws_barrier();
-    }
+    };
+    if (ntiles > 0) run_tile(std::true_type{}, 0);
+    for (int tile = 1; tile < ntiles; ++tile) run_tile(std::false_type{}, tile);
     WS_STAMP(15);
 }
 
