@@ -885,40 +885,49 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk)
     }
 }
 
-// LePE conv weight/bias gradient partial slabs from global memory; one workgroup per (branch, window, head)
+// LePE conv weight / bias gradient partial slabs from global memory (large-window path).  One workgroup per (branch, window,
+// head, token slice): LW_SUB slices per window, each with its own slab row.  A thread owns ONE output group -- (tap, 16-B
+// channel chunk): tid & 7 = chunk, (tid >> 3) & 15 = tap slot (10 of 16 used; tap 9 = bias) -- and walks the tokens of its half
+// of the slice, so nothing is reduced across lanes; the two halves meet in LDS.  v is re-read nine times by its own window
+// only (L1 / L2 resident).  (The first version -- one thread per (token slot, channel), scalar loads -- took 69 us per launch
+// at 384 x 384, 8 % of that step.)
+constexpr int LW_SUB = 4;
 __global__ __launch_bounds__(256) void lepe_wgrad_kernel(AttnParams p) {
-    __shared__ float scratch[8 * 10 * HD];
-    const WgInfo w = decode_wg(p, blockIdx.x);
+    __shared__ __attribute__((aligned(16))) float red[16 * 8 * 4];
+    const int sub = (int)blockIdx.x % LW_SUB;
+    const WgInfo w = decode_wg(p, (int)blockIdx.x / LW_SUB);
     const AttnBranch& br = p.br[w.bi];
-    const int tid = threadIdx.x, d = tid & 31, tg = tid >> 5;
+    const int tid = threadIdx.x;
+    const int c4 = tid & 7, tap = (tid >> 3) & 15, half = tid >> 7;
     const int L = p.reso * p.reso, C3 = 3 * p.C, N = w.N;
     const int ch0 = br.c0 + w.g * p.hd;
-    const float* v_b = p.qkv + (long)w.b * L * C3 + 2 * p.C + ch0 + d;
-    const float* dy_b = p.dy + (long)w.b * L * p.C + ch0 + d;
-    float a[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) a[i] = 0.f;
-    for (int t = tg; t < N && d < p.hd; t += 8) {
-        const int rr = t / br.W_sp, cc = t - rr * br.W_sp;
-        const float g = dy_b[(long)token_of(br, w, p.reso, t) * p.C];
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
+    const bool live = tap < 10 && 4 * c4 < p.hd;
+    const float* v_b = p.qkv + (long)w.b * L * C3 + 2 * p.C + ch0 + 4 * c4;
+    const float* dy_b = p.dy + (long)w.b * L * p.C + ch0 + 4 * c4;
+    const int ky = tap / 3, kx = tap - ky * 3;            // (tap 9: ky = 3, unused)
+    const int n_part = (N + 2 * LW_SUB - 1) / (2 * LW_SUB);
+    const int t0 = min(N, (2 * sub + half) * n_part), t1 = min(N, t0 + n_part);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+#pragma unroll 4
+        for (int t = t0; t < t1; ++t) {
+            const int rr = t / br.W_sp, cc = t - rr * br.W_sp;
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(dy_b + (long)token_of(br, w, p.reso, t) * p.C);
+            if (tap == 9) {
+                acc += g4;
+            } else {
                 const int r2 = rr + ky - 1, c2 = cc + kx - 1;
                 if ((unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp)
-                    a[ky * 3 + kx] += g * v_b[(long)token_of(br, w, p.reso, r2 * br.W_sp + c2) * C3];
+                    acc += g4 * *reinterpret_cast<const f32x4*>(v_b + (long)token_of(br, w, p.reso, r2 * br.W_sp + c2) * C3);
             }
-        a[9] += g;
+        }
     }
-#pragma unroll
-    for (int i = 0; i < 10; ++i) scratch[(tg * 10 + i) * HD + d] = a[i];
+    if (half == 1) *reinterpret_cast<f32x4*>(&red[(tap * 8 + c4) * 4]) = acc;
     __syncthreads();
-    for (int i = tid; i < 10 * HD; i += 256) {
-        float s = 0.f;
+    if (half == 0 && live) {
+        acc += *reinterpret_cast<const f32x4*>(&red[(tap * 8 + c4) * 4]);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s += scratch[k * 10 * HD + i];
-        store_lepe_partial(p, br, w, 0, i, s);
+        for (int e = 0; e < 4; ++e) store_lepe_partial(p, br, w, sub, tap * HD + 4 * c4 + e, acc[e]);
     }
 }
 
@@ -1052,6 +1061,11 @@ int launch_bwd2(const AttnParams& p, int nwg, hipStream_t st) {
 
 long long* g_attn_stamps = nullptr;     // debug only (cswin_debug_set_attn_stamps)
 
+inline bool force_two_pass() {          // tuning aid: the large-window backward for every window size
+    static const bool f = getenv("CSWIN_ATTN_BWD_TWO_PASS") != nullptr;
+    return f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1093,8 +1107,8 @@ size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* 
     AttnParams p = {};
     int nt, nwg;
     if (fill_params(p, "attn_bwd_workspace", B, reso, C, nbranch, heads, idx, split, 0.f, &nt, &nwg)) return 0;
-    // LePE partial slabs + delta (B, heads, L) (used by the two-pass path)
-    size_t n = (size_t)nwg * 10 * HD;
+    // LePE partial slabs (LW_SUB rows per window on the two-pass path) + delta (B, heads, L) (used by the two-pass path)
+    size_t n = (size_t)nwg * 10 * HD * ((nt > 7 || force_two_pass()) ? LW_SUB : 1);
     n += (size_t)B * p.heads_total * reso * reso;
     return n * sizeof(float);
 }
@@ -1111,18 +1125,17 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
     CSWIN_REQUIRE(qkv && lse && dy && dqkv && lepe_w && dlepe_w && dlepe_b, CSWIN_ERR_SHAPE, "attn_bwd: null pointer");
     CSWIN_REQUIRE(workspace && ws_bytes >= cswin_attn_bwd_workspace(B, reso, C, nbranch, heads, idx, split), CSWIN_ERR_WORKSPACE, "attn_bwd: workspace too small");
     CSWIN_REQUIRE(y && lepe_b, CSWIN_ERR_SHAPE, "attn_bwd: the forward output y and lepe_b are required");
-    static const bool force_two_pass = getenv("CSWIN_ATTN_BWD_TWO_PASS") != nullptr;     // tuning aid
-    const bool two_pass = nt > 7 || force_two_pass;
-    p.slab_rows = 1;
+    const bool two_pass = nt > 7 || force_two_pass();
+    p.slab_rows = two_pass ? LW_SUB : 1;
     p.ds_stride = ds_stride_for(p.br[0].H_sp * p.br[0].W_sp);
     for (int i = 0; i < nbranch; ++i) {
         p.br[i].lepe_w = lepe_w[i];
         p.br[i].lepe_b = lepe_b[i];
-        p.br[i].dw_part = (float*)workspace + (size_t)p.br[i].wg_begin * 10 * HD;
+        p.br[i].dw_part = (float*)workspace + (size_t)p.br[i].wg_begin * 10 * HD * p.slab_rows;
     }
     p.stamps = g_attn_stamps;
     p.y_in = y;
-    p.delta = (float*)workspace + (size_t)nwg * 10 * HD;
+    p.delta = (float*)workspace + (size_t)nwg * 10 * HD * p.slab_rows;
     p.qkv = qkv; p.lse = const_cast<float*>(lse); p.dy = dy; p.dqkv = dqkv;
     hipStream_t st = (hipStream_t)stream;
     if (two_pass) {
@@ -1132,7 +1145,7 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
         hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items * 8 + 255) / 256)), dim3(256), 0, st, p);
         hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(nwg * nblk), dim3(256), 0, st, p, nblk);
         hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(nwg * nblk), dim3(256), 0, st, p, nblk);
-        hipLaunchKernelGGL(lepe_wgrad_kernel, dim3(nwg), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(lepe_wgrad_kernel, dim3(nwg * LW_SUB), dim3(256), 0, st, p);
         rc = CSWIN_OK;
     } else {
         switch (nt) {
