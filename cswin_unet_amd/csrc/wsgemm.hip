@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "gemm_epilogue.h"
 
@@ -52,6 +53,27 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int... Is, class F>
+__device__ __forceinline__ void ws_static_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void ws_static_for(F&& f) { ws_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// First tile of a workgroup: operations YOUNGER than the DMA of step kc + 1 when step kc's MFMAs have been issued (the counted
+// wait may leave that many in flight).  Issue order: prologue = DMA(0 .. D-2), weight chunks 0 and 1, bias; step j = DMA(j + D - 1),
+// weight chunk j + 2 (chunks exist for indices < nkc; q DMA and nwc weight load instructions each).  vmcnt is a 6-bit field.
+constexpr int ws_first_tile_inflight(int kc, int nkc, int d, int q, int nwc) {
+    int n = 0;
+    if (kc + 1 <= d - 2) {
+        n = (d - 2 - (kc + 1)) * q + (nkc >= 2 ? 2 : 1) * nwc + 1;
+        for (int j = 0; j <= kc; ++j) n += q + (j + 2 < nkc ? nwc : 0);
+    } else {
+        const int j0 = kc + 2 - d;
+        n = (j0 + 2 < nkc ? nwc : 0);
+        for (int j = j0 + 1; j <= kc; ++j) n += q + (j + 2 < nkc ? nwc : 0);
+    }
+    return n > 63 ? 63 : n;
 }
 
 // ring depth: 8-wave workgroups own the CU's LDS (<= 133 KB); two 4-wave workgroups per CU get <= 80 KB each
@@ -221,29 +243,34 @@ __global__ __launch_bounds__(64 * NWN * NWK, 2) void ws_gemm_kernel(WsParams p) 
     // every wave's DMA is in the CU's memory queue before any wave's weight loads (the texture path serves requests in arrival
     // order: without this barrier the DMA of the last waves sit behind the 32-KB weight streams of the first)
     ws_barrier();
-    constexpr int NWL = BTRANS ? KS / 2 : KS / 8;          // weight load instructions per lane
-    // the weight slice of this wave -> registers: breg[4 * (koff / 8) + s] = Bm(wk*KS + koff + 4 lh + s, ncol0 + li)
+    // The weight slice of this wave lives in registers for the whole launch: breg[4 * (koff / 8) + s] = Bm(wk*KS + koff + 4 lh + s,
+    // ncol0 + li).  It is STREAMED in: the 32-k chunk of step c is requested two steps ahead (chunks 0 and 1 here, chunk c + 2
+    // at the top of step c of the first tile), so the launch does not open with every CU pulling its whole 32 - 256 KB slice
+    // through L2 at once (measured: that burst delayed the first activations of every workgroup to ~15 k cycles).
+    // Columns past N (last n-group) re-read column N - 1: their products are never stored.  No select on the loaded values:
+    // it would make hipcc wait for the load on the spot instead of at the MFMA that first uses it.
+    constexpr int NWC = BTRANS ? 16 : 4;                   // weight load instructions per lane and chunk
     float breg[KS / 2];
-    {
-        // columns past N (last n-group) re-read column N - 1: their products are never stored.  No select on the loaded
-        // values: it would make hipcc wait for every weight load right here instead of at the MFMA that first uses it.
-        const int n = min(ncol0 + li, p.N - 1);
-        if constexpr (!BTRANS) {
-            const float* wrow = p.W + (long)n * p.ldw + wk * KS + 4 * lh;
+    const int wn_col = min(ncol0 + li, p.N - 1);
+    const float* wbase = BTRANS ? p.W + (long)(wk * KS + 4 * lh) * p.ldw + wn_col : p.W + (long)wn_col * p.ldw + wk * KS + 4 * lh;
+    auto load_w_chunk = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if constexpr (c < NKC) {
 #pragma unroll
-            for (int g = 0; g < KS / 8; ++g) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + 8 * g);
+            for (int g = 4 * c; g < 4 * c + 4; ++g) {
+                if constexpr (!BTRANS) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + 8 * g);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) breg[4 * g + s] = v[s];
+                    for (int e = 0; e < 4; ++e) breg[4 * g + e] = v[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) breg[4 * g + e] = wbase[(long)(8 * g + e) * p.ldw];
+                }
             }
-        } else {
-            const float* wcol = p.W + (long)(wk * KS + 4 * lh) * p.ldw + n;
-#pragma unroll
-            for (int g = 0; g < KS / 8; ++g)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) breg[4 * g + s] = wcol[(long)(8 * g + s) * p.ldw];
         }
-    }
+    };
+    load_w_chunk(std::integral_constant<int, 0>{});
+    load_w_chunk(std::integral_constant<int, 1>{});
     // bias of this wave's columns in the epilogue's lane layout (lane owns columns ncol0 + 4 (lane & 7) .. +3): loaded once,
     // unconditionally (from the weight matrix when there is no bias: the value is then discarded)
     f32x4 bias_raw;
@@ -253,7 +280,8 @@ __global__ __launch_bounds__(64 * NWN * NWK, 2) void ws_gemm_kernel(WsParams p) 
         has_bias = p.epi.bias && n < p.N;
         bias_raw = *reinterpret_cast<const f32x4*>(has_bias ? p.epi.bias + n : p.W);     // selected where it is used (epilogue)
     }
-    constexpr int N_PRO = (D - 2) * Q + NWL + 1 > 63 ? 63 : (D - 2) * Q + NWL + 1;     // vmcnt is a 6-bit field
+    constexpr int NW_PRO = (NKC >= 2 ? 2 : 1) * NWC + 1;   // weight chunks 0, 1 and the bias load
+    constexpr int N_PRO = (D - 2) * Q + NW_PRO > 63 ? 63 : (D - 2) * Q + NW_PRO;       // vmcnt is a 6-bit field
     if (total > D - 2) ws_wait_vmcnt<N_PRO>();             // my DMA of step 0 has landed (everything younger may be in flight)
     else ws_wait_vmcnt<0>();
     WS_STAMP(1);
@@ -273,13 +301,14 @@ __global__ __launch_bounds__(64 * NWN * NWK, 2) void ws_gemm_kernel(WsParams p) 
         WsEpiRegs<EPI> er;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[0][0][e] = acc[1][0][e] = 0.f;
-#pragma unroll
-        for (int kc = 0; kc < NKC; ++kc, ++s) {
+        ws_static_for<NKC>([&](auto kct) {
+            constexpr int kc = decltype(kct)::value;
             {
                 int si = s + D - 1;                        // laundered: keeps hipcc from specialising (and hoisting) the DMA
                 asm volatile("" : "+s"(si));               // addresses of every unrolled step
                 if (si < total) issue(si);
             }
+            if constexpr (FIRST) load_w_chunk(std::integral_constant<int, kc + 2>{});      // two steps ahead of its MFMAs
             if (kc == NKC - 1 && wk == 0 && active)
                 ws_epi_prefetch<EPI>(er, p.epi, row_end, p.N, row_base + tile * WS_BM, ncol0, lane, full);
             if (active) {
@@ -297,14 +326,19 @@ __global__ __launch_bounds__(64 * NWN * NWK, 2) void ws_gemm_kernel(WsParams p) 
                             acc[hm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][e], breg[kc * 16 + kk * 4 + e], acc[hm][0], 0, 0, 0);
                 }
             }
-            // my DMA of step s + 1 has landed once at most the (D - 2) later stages are outstanding.  The tile's last step
-            // retires everything instead (the epilogue operands just loaded sit behind the DMA in the in-order counter).
-            if (kc == NKC - 1) __builtin_amdgcn_s_waitcnt(0x0F70);
-            else if (s + D - 1 >= total) ws_wait_vmcnt<0>();
-            else if (FIRST && kc + 1 <= D - 2) ws_wait_vmcnt<N_PRO>();      // step kc + 1 was issued in the prologue, ahead of the weights
-            else ws_wait_vmcnt<(D - 2) * Q>();
-            if (kc + 1 < NKC) ws_barrier();                // (the tile's last barrier comes after the epilogue)
-        }
+            // my DMA of step s + 1 has landed once at most the (D - 2) later stages (first tile: plus the weight chunks requested
+            // behind it) are outstanding.  The tile's last step retires everything instead (the epilogue operands just loaded
+            // sit behind the DMA in the in-order counter).
+            if constexpr (kc == NKC - 1) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+            } else {
+                if (s + D - 1 >= total) ws_wait_vmcnt<0>();
+                else if constexpr (FIRST) ws_wait_vmcnt<ws_first_tile_inflight(kc, NKC, D, Q, NWC)>();
+                else ws_wait_vmcnt<(D - 2) * Q>();
+                ws_barrier();                              // (the tile's last barrier comes after the epilogue)
+            }
+            ++s;
+        });
         WS_STAMP(3 + 2 * tile);
         // ---- k-groups -> one accumulator (binary tree through LDS, native C/D layout) ----
         if constexpr (NWK > 1) {
@@ -420,13 +454,20 @@ static int g_ws_enabled = -1;       // debug / tuning aid only (cswin_debug_set_
 extern "C" void cswin_debug_set_ws_gemm(int on) { g_ws_enabled = on; }
 
 int cswin_ws_gemm(int mode, int epi_mode, const float* A, const float* W, const void* epilogue, int M, int N, int R, void* stream) {
-    // Opt-in (CSWIN_WS_GEMM=1 / cswin_debug_set_ws_gemm): on the model's shapes this family ties the tiled one within +-10 %
-    // (profiles/round2_notes.md, "Weight-stationary GEMM"), so the default path stays the tiled family.
-    if (g_ws_enabled < 0) g_ws_enabled = getenv("CSWIN_WS_GEMM") ? atoi(getenv("CSWIN_WS_GEMM")) != 0 : 0;
+    // CSWIN_WS_GEMM / cswin_debug_set_ws_gemm: 0 (default) = never, 1 = wherever a layout exists (A/B runs), 2 = where the cost
+    // model predicts this family within 1.7x of the pure-MFMA time and the output is at least 128 columns wide -- the shapes on
+    // which it measured faster than the tiled family stand-alone (profiles/round2_ws_gemm_vs_tiled.txt: -0.19 ms per step
+    // picking the better of the two per shape).  Inside the training step that gain does not materialise (13.25 / 13.28 /
+    // 13.46 ms per step for modes 0 / 2 / 1), so the default path stays the tiled family.
+    if (g_ws_enabled < 0) g_ws_enabled = getenv("CSWIN_WS_GEMM") ? atoi(getenv("CSWIN_WS_GEMM")) : 0;
     if (!g_ws_enabled) return 1;
     if (M < 512 || N % 4 != 0 || R % 4 != 0 || !aligned16(A) || !aligned16(W)) return 1;
     WsCfg c;
     if (!ws_choose(M, N, R, epi_mode == EPI_RES || epi_mode == EPI_GELUBWD, &c)) return 1;
+    if (g_ws_enabled == 2) {
+        const double ideal = 2.0 * M * (double)N * R / (256.0 * 256.0);       // cycles at 64 flop / clk / SIMD on 256 CUs
+        if (N < 128 || c.cost > 1.7 * ideal) return 1;
+    }
     if (const char* f = getenv("CSWIN_WS_LAYOUT")) {        // tuning aid: "nwn,nwk" forces a wave layout where it fits R
         int a = 0, b = 0;
         if (sscanf(f, "%d,%d", &a, &b) == 2 && b > 0 && R % b == 0) {
