@@ -717,10 +717,25 @@ def test_linear_bf16_operands(ops, bf16_matmul, M, Nn, K):
     assert errs["y"] > 1e-5          # the bf16 path really ran (fp32 MFMA would be ~1e-6)
 
 
+def _rel_l2(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).pow(2).sum().sqrt() / (ref.pow(2).sum().sqrt() + 1e-300))
+
+
+# Derived bf16 bounds.  One GEMM with both operands rounded to bf16 (RNE: relative error uniform in +-2^-9, sigma 2^-9 / sqrt 3)
+# has a relative L2 error of sqrt(2) * 2^-9 / sqrt(3) = 1.6e-3.  A forward pass chains ~60 such contractions (26 blocks x 4 Linears
+# behind residual connections that dilute each contribution) and a gradient ~120; independent errors add in quadrature:
+# 1.6e-3 * sqrt(60) = 1.2e-2 for the logits, 1.6e-3 * sqrt(120) = 1.8e-2 for a gradient.  Bounds = 2.5x those (LayerNorm rescaling
+# and the softmax make some links amplify): logits 3e-2, gradients 5e-2 in relative L2 (measured: 1.2e-2 and 0.7 - 1.9e-2).  The
+# elementwise maximum of the logits over ~1e6 elements sits 5 - 6 sigma out (bound 6x the L2 one; measured 6.9e-2); parameter
+# gradients are heavy-tailed (elements of many times the RMS carry proportionally larger absolute errors), so for them only the
+# L2 bound is meaningful.
+BF16_LOGITS_L2, BF16_GRAD_L2 = 3e-2, 5e-2
+
+
 def test_model_bf16_operands_training_step(N, ops, golden, bf16_matmul):
-    """Whole model, one step, bf16 GEMM / conv operands against the fp32 reference outputs (g5).  The rounding of ~60 chained
-    contractions accumulates: observed max|diff|/rms is 7.3e-2 on the logits and 1.2e-1 .. 2.7e-1 on parameter gradients; the
-    bounds below are those observations x 1.5 - 2 (stated, as SURVEY 8c asks for the bf16 configs), the loss is within 2 %."""
+    """Whole model, one step, bf16 GEMM / conv operands against the fp32 reference outputs (g5: strided samples of the reference
+    tensors), relative L2 over the samples and elementwise maximum, with the derived bounds above; the loss within 1 %."""
     g = golden("g5_model")
     net = _golden_model(N).train()
     x = T(det_normal("model.x", (2, 1, 224, 224))).repeat(1, 3, 1, 1)
@@ -731,19 +746,65 @@ def test_model_bf16_operands_training_step(N, ops, golden, bf16_matmul):
         a = t.detach().float().cpu().numpy().reshape(-1)
         ref, stride = g[prefix + "vals"], int(g[prefix + "stride"])
         rms = float(np.sqrt(float(g[prefix + "sqsum"]) / a.size)) + 1e-30
-        err = float(np.abs(a[::stride] - ref).max()) / rms
+        d = a[::stride].astype(np.float64) - ref
+        l2, mx = float(np.sqrt(np.mean(d * d))) / rms, float(np.abs(d).max()) / rms
         with open(LOG, "a") as f:
-            f.write(f"model_bf16.{prefix} {err:.3e}\n")
-        return err
+            f.write(f"model_bf16.{prefix} l2 {l2:.3e} max {mx:.3e}\n")
+        return l2, mx
 
-    e = packed_err(logits, "logits.")
-    assert 1e-4 < e < 0.15, e
+    l2, mx = packed_err(logits, "logits.")
+    assert 1e-4 < l2 < BF16_LOGITS_L2 and mx < 6 * BF16_LOGITS_L2, (l2, mx)
     loss, stats = ops.ce_dice_loss(logits, lab)
-    assert abs(float(loss) - float(g["loss"])) < 2e-2 * abs(float(g["loss"]))
+    assert abs(float(loss) - float(g["loss"])) < 1e-2 * abs(float(g["loss"]))
     loss.backward()
     params = dict(net.named_parameters())
     for n in ["stage3.4.qkv.weight", "merge2.conv.weight", "upsample1.encoder.weight", "output.weight", "concat_linear3.weight"]:
-        assert packed_err(params[n].grad, f"grad.{n}.") < 0.4, n
+        l2, mx = packed_err(params[n].grad, f"grad.{n}.")
+        assert l2 < BF16_GRAD_L2, (n, l2, mx)
+
+
+def _bf16_step_vs_oracle(N, ops, cfg, net, img, lab, tag, grads):
+    logits = net(T(img))
+    loss, _ = ops.ce_dice_loss(logits, T(lab))
+    loss.backward()
+    P = O.golden_params(cfg)
+    ref_logits = O.cswin_forward(P, torch.from_numpy(img), cfg)
+    ref_loss, _, _ = O.ce_dice_loss(ref_logits, torch.from_numpy(lab))
+    ref_loss.backward()
+    e = _rel_l2(logits, ref_logits)
+    with open(LOG, "a") as f:
+        f.write(f"{tag}.logits l2 {e:.3e}\n")
+    assert 1e-4 < e < BF16_LOGITS_L2, e
+    assert abs(float(loss) - float(ref_loss)) < 1e-2 * abs(float(ref_loss))
+    params = dict(net.named_parameters())
+    for n in grads:
+        e = _rel_l2(params[n].grad, P[n].grad)
+        with open(LOG, "a") as f:
+            f.write(f"{tag}.grad.{n} l2 {e:.3e}\n")
+        assert e < BF16_GRAD_L2, (n, e)
+
+
+def test_model_bf16_384_step_vs_oracle(N, ops, bf16_matmul):
+    """BASELINE configs[3] in its own precision: 384 x 384 (split [1,2,12,12]: large-window attention paths), bf16 operands, B = 1,
+    against the fp32 oracle with the derived bounds."""
+    cfg = dict(O.TINY_224, img_size=384, split_size=(1, 2, 12, 12))
+    net = N.CSWinTransformer(img_size=384, num_classes=9, embed_dim=64, depth=[1, 2, 9, 1], split_size=[1, 2, 12, 12],
+                             num_heads=[2, 4, 8, 16], qkv_bias=True).to(DEV)
+    fill_state_dict(net).train()
+    _bf16_step_vs_oracle(N, ops, cfg, net, det_normal("model384.x", (1, 3, 384, 384)), det_labels("model384.lab", (1, 384, 384), 9),
+                         "bf16_384", ["stage3.4.qkv.weight", "stage3.4.attns.1.get_v.weight", "stage_up3.2.proj.weight",
+                                      "merge2.conv.weight", "upsample1.encoder.weight", "output.weight"])
+
+
+def test_model_bf16_base_width_step_vs_oracle(N, ops, bf16_matmul):
+    """BASELINE configs[4] widths (embed_dim 96, head dim 24) with a short depth in bf16 operands, B = 2, against the fp32 oracle."""
+    cfg = dict(O.TINY_224, embed_dim=96, depth=(1, 2, 2, 1), num_heads=(4, 8, 16, 32))
+    net = N.CSWinTransformer(img_size=224, num_classes=9, embed_dim=96, depth=[1, 2, 2, 1], split_size=[1, 2, 7, 7],
+                             num_heads=[4, 8, 16, 32], qkv_bias=True).to(DEV)
+    fill_state_dict(net).train()
+    _bf16_step_vs_oracle(N, ops, cfg, net, det_normal("modelbase.x", (2, 3, 224, 224)), det_labels("modelbase.lab", (2, 224, 224), 9),
+                         "bf16_base", ["stage3.1.qkv.weight", "stage2.0.mlp.fc1.weight", "merge3.conv.weight", "stage_up2.1.proj.weight",
+                                       "upsample2.encoder.weight", "output.weight"])
 
 
 # ------------------------------------------------------------------------------------------------------------------
