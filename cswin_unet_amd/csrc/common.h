@@ -176,18 +176,6 @@ static __global__ __launch_bounds__(256) void rows_sum_conv_kernel(cswin_reduce_
     }
 }
 
-static __global__ __launch_bounds__(256) void rows_sum_kernel(cswin_reduce_job job) {
-    __shared__ float red[RS_G][RS_COLS + 1];
-    rows_sum_block(job, blockIdx.x, red);
-}
-
-static inline void launch_rows_sum(const float* part, float* out, float* out2, long n_first, long n, int rows, long stride,
-                                   hipStream_t st) {
-    cswin_reduce_job job = {part, out, out2, n_first, n, stride, rows, 0};
-    job.reserved = reduce_job_vec_ok(job);
-    hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((n + RS_COLS - 1) / RS_COLS)), dim3(256), 0, st, job);
-}
-
 extern "C" {
 typedef struct cswin_wgrad_desc {
     const float* dy;         // (M, N)
@@ -209,11 +197,52 @@ struct ReduceJobs {
     int njobs;
 };
 
+// Few slab rows (split-K weight gradients: 4 - 16 slabs of up to 1 M columns): the 16 row groups of rows_sum_block would leave
+// three quarters of the threads without a row.  Here a thread owns four columns and walks all rows (every load of the
+// workgroup is a full 4-KB line set, up to eight in flight per thread); one workgroup covers 1024 columns.
+constexpr int RS_FEW_ROWS = 16, RS_FEW_COLS = 1024;
+__device__ __forceinline__ void rows_sum_few(const cswin_reduce_job& job, long blk) {
+    const long i0 = blk * RS_FEW_COLS + 4 * threadIdx.x;
+    if (i0 >= job.n) return;
+    const float* base = job.part + i0;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    int r = 0;
+    for (; r + 1 < job.rows; r += 2) {
+        s0 += *reinterpret_cast<const f32x4*>(base + (long)r * job.stride);
+        s1 += *reinterpret_cast<const f32x4*>(base + (long)(r + 1) * job.stride);
+    }
+    if (r < job.rows) s0 += *reinterpret_cast<const f32x4*>(base + (long)r * job.stride);
+    s0 += s1;
+    if (job.out2 && i0 >= job.n_first) *reinterpret_cast<f32x4*>(job.out2 + (i0 - job.n_first)) = s0;
+    else *reinterpret_cast<f32x4*>(job.out + i0) = s0;
+}
+// reserved bit 1 (set by cswin_rows_sum_multi): this job runs in the few-rows mode (needs bit 0 and 16-B aligned outputs)
+static inline int reduce_job_few_ok(const cswin_reduce_job& j) {
+    return reduce_job_vec_ok(j) && j.rows <= RS_FEW_ROWS && j.n >= 4 * RS_FEW_COLS && ((uintptr_t)j.out % 16 == 0) &&
+           (!j.out2 || ((uintptr_t)j.out2 % 16 == 0));
+}
+
+static __global__ __launch_bounds__(256) void rows_sum_kernel(cswin_reduce_job job) {
+    __shared__ float red[RS_G][RS_COLS + 1];
+    if (job.reserved & 2) rows_sum_few(job, blockIdx.x);
+    else rows_sum_block(job, blockIdx.x, red);
+}
+
+static inline void launch_rows_sum(const float* part, float* out, float* out2, long n_first, long n, int rows, long stride,
+                                   hipStream_t st) {
+    cswin_reduce_job job = {part, out, out2, n_first, n, stride, rows, 0};
+    const int few = reduce_job_few_ok(job);
+    job.reserved = reduce_job_vec_ok(job) | (few ? 2 : 0);
+    const long cols = few ? RS_FEW_COLS : RS_COLS;
+    hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((n + cols - 1) / cols)), dim3(256), 0, st, job);
+}
+
 static __global__ __launch_bounds__(256) void rows_sum_multi_kernel(ReduceJobs J) {
     __shared__ float red[RS_G][RS_COLS + 1];
     int k = 0;
     while (k + 1 < J.njobs && (int)blockIdx.x >= J.first_block[k + 1]) ++k;
-    rows_sum_block(J.j[k], blockIdx.x - J.first_block[k], red);
+    if (J.j[k].reserved & 2) rows_sum_few(J.j[k], blockIdx.x - J.first_block[k]);
+    else rows_sum_block(J.j[k], blockIdx.x - J.first_block[k], red);
 }
 
 // run `job` now, or hand it to the caller (deferred != NULL) to be batched by cswin_rows_sum_multi

@@ -988,9 +988,10 @@ int cswin_rows_sum_multi(const cswin_reduce_job* jobs, int njobs, void* stream) 
     for (int i = 0; i < njobs; ++i) {
         CSWIN_REQUIRE(jobs[i].part && jobs[i].out && jobs[i].n > 0 && jobs[i].rows > 0, CSWIN_ERR_SHAPE, "rows_sum_multi: bad job %d", i);
         J.j[i] = jobs[i];
-        J.j[i].reserved = reduce_job_vec_ok(jobs[i]);
+        const int few = reduce_job_few_ok(jobs[i]);
+        J.j[i].reserved = reduce_job_vec_ok(jobs[i]) | (few ? 2 : 0);
         J.first_block[i] = blocks;
-        blocks += (int)((jobs[i].n + RS_COLS - 1) / RS_COLS);
+        blocks += few ? (int)((jobs[i].n + RS_FEW_COLS - 1) / RS_FEW_COLS) : (int)((jobs[i].n + RS_COLS - 1) / RS_COLS);
     }
     J.first_block[njobs] = blocks;
     J.njobs = njobs;
