@@ -87,9 +87,9 @@ def attention_roofline(batch, cfg, img_size=224):
         nbytes = lib().cswin_attn_bwd_workspace(batch, reso, C, nb, ha, ia, split[si])
         ws = torch.empty(nbytes // 4 + 4, device=dev)
         t_f = _graph_time(lambda: call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(lse), batch, reso, C, nb, ha, ia,
-                                       split[si], 0.0, stream()))
+                                       split[si], 0.0, 0, stream()))
         t_b = _graph_time(lambda: call("cswin_attn_bwd", ptr(qkv), pa(w), pa(b), ptr(lse), ptr(y), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws),
-                                       nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, None, stream()))
+                                       nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, None, 0, stream()))
         flops_f = 4.0 * L * n_tok * C * batch
         n_blocks = 2 * depth[si]
         bytes_f, bytes_b = 16.0 * L * C * batch, 28.0 * L * C * batch
@@ -136,8 +136,8 @@ def gemm_family_roofline(batch, cfg, img_size=224):
             y, dx, dw, db = (torch.empty(*sh, device="cuda") for sh in ((M, N), (M, K), (N, K), (N,)))
             nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
             ws = torch.empty(nbytes // 4 + 4, device="cuda")
-            t = _graph_time(lambda: call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, precision(), stream()))
-            t += _graph_time(lambda: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, precision(), stream()))
+            t = _graph_time(lambda: call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, precision(), 0, stream()))
+            t += _graph_time(lambda: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, precision(), 0, stream()))
             t += _graph_time(lambda: call("cswin_linear_bwd_weight", ptr(dy), ptr(x), None, 0, None, 1, ptr(dw), ptr(db), ptr(ws), nbytes,
                                           M, N, K, None, precision(), stream()))
             tot_t += 2 * depth[si] * t

@@ -22,6 +22,16 @@ def set_matmul_precision(mode):
     return "bf16" if _lib.set_precision(_PRECISIONS[mode]) == 1 else "fp32"
 
 
+def set_activation_storage(dtype):
+    """"bf16" (default) or "fp32": how a CSWinBlock stores qkv, the MLP hidden activations and their gradients WHEN the matmul
+    precision is bf16 (with fp32 matmuls storage is always fp32).  The residual stream, LayerNorm outputs, statistics, master
+    weights and all accumulation stay fp32 either way.  Returns the previous setting."""
+    from . import _lib
+    if dtype not in ("bf16", "fp32"):
+        raise ValueError(f"activation storage {dtype!r}: expected 'bf16' or 'fp32'")
+    return "bf16" if _lib.set_act_bf16(dtype == "bf16") else "fp32"
+
+
 def get_matmul_precision():
     from . import _lib
     return "bf16" if _lib.precision() == 1 else "fp32"

@@ -20,16 +20,16 @@ SIGNATURES = {
     "cswin_last_error": (c_char_p, []),
     "cswin_abi_version": (I, []),
     "cswin_device_ok": (I, []),
-    "cswin_attn_fwd": (I, [P, P, P, P, P, I, I, I, I, P, P, I, F, P]),
+    "cswin_attn_fwd": (I, [P, P, P, P, P, I, I, I, I, P, P, I, F, I, P]),
     "cswin_attn_bwd_workspace": (SZ, [I, I, I, I, P, P, I]),
-    "cswin_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, I, I, P, P, I, F, P, P]),
+    "cswin_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, I, I, P, P, I, F, P, I, P]),
     "cswin_img2windows": (I, [P, P, I, I, I, I, I, I, P]),
     "cswin_windows2img": (I, [P, P, I, I, I, I, I, I, P]),
     "cswin_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
     "cswin_layernorm_bwd_workspace": (SZ, [I, I]),
     "cswin_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, P, P]),
-    "cswin_linear_fwd": (I, [P, P, I, P, P, P, P, P, P, I, I, I, I, I, P]),
-    "cswin_linear_bwd_data": (I, [P, P, P, P, I, P, P, I, P, I, I, I, I, P]),
+    "cswin_linear_fwd": (I, [P, P, I, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "cswin_linear_bwd_data": (I, [P, P, P, P, I, P, P, I, P, I, I, I, I, I, P]),
     "cswin_linear_bwd_weight_workspace": (SZ, [I, I, I]),
     "cswin_linear_bwd_weight": (I, [P, P, P, I, P, I, P, P, P, SZ, I, I, I, P, I, P]),
     "cswin_linear_bwd_weight_batch": (I, [P, I, P, P]),
@@ -63,7 +63,7 @@ class WgradDesc(ctypes.Structure):
     """Mirror of cswin_wgrad_desc (include/cswin_hip.h)."""
     _fields_ = [("dy", c_void_p), ("x", c_void_p), ("row_scale", c_void_p), ("dw", c_void_p), ("dbias", c_void_p),
                 ("workspace", c_void_p), ("ws_bytes", c_size_t), ("rows_per_sample", c_int), ("M", c_int), ("N", c_int),
-                ("K", c_int), ("precision", c_int)]
+                ("K", c_int), ("precision", c_int), ("io_bf16", c_int)]
 
 
 class ReduceJob(ctypes.Structure):
@@ -77,11 +77,23 @@ _lib = None
 # Matmul precision of the Linear / convolution entry points: an ARGUMENT of every call (0 = exact fp32 MFMA, 1 = bf16 operands,
 # bf16 MFMA, fp32 accumulate), not a library global.  The Python package keeps the caller's choice here and ops.py passes it.
 PREC_FP32, PREC_BF16 = 0, 1
-_state = {"precision": PREC_FP32}
+_state = {"precision": PREC_FP32, "act_bf16": True}
 
 
 def precision():
     return _state["precision"]
+
+
+def act_bf16():
+    """bf16 STORAGE of the block-internal activations (qkv, the MLP hidden tensors and their gradients): on whenever the matmul
+    precision is bf16, unless switched off with set_act_bf16(False)."""
+    return _state["precision"] == PREC_BF16 and _state["act_bf16"]
+
+
+def set_act_bf16(on):
+    prev = _state["act_bf16"]
+    _state["act_bf16"] = bool(on)
+    return prev
 
 
 def set_precision(mode):

@@ -59,8 +59,33 @@ struct AttnParams {
     int ds_stride;         // fused backward: LDS row stride of the dS image (>= N, = 4 mod 8: conflict-free column writes)
     int slab_rows;         // LePE gradient slab rows per window (1 on every current path)
     long long* stamps;     // debug (cswin_debug_set_attn_stamps): [workgroup][8] s_memtime stamps of wave 0, or NULL
+    int qkv_bf16;          // qkv and dqkv are STORED as bf16 (bf16 activation storage); all arithmetic stays fp32
     AttnBranch br[2];
 };
+
+// q / k / v and their gradients may be stored as bf16.  Addresses are computed in ELEMENTS on fp32-typed pointers (a plain
+// fp32 access when qkv_bf16 == 0); for bf16 storage the element offset is re-applied to the bf16 base.
+typedef __bf16 attn_bf16x4 __attribute__((ext_vector_type(4)));
+// Storage is a COMPILE-TIME parameter of every kernel that touches q / k / v (Q16): a run-time choice between 8-B and 16-B loads
+// splits the load sequences into basic blocks whose loads then wait for one another.  Loads come in two halves: ldq_raw issues
+// the load (4 fp32, or 4 bf16 as two raw dwords) and qcv widens it where the value is consumed.  The raw bf16 pair is an
+// INTEGER vector on purpose: hipcc 7.2 miscompiles bit casts of the elements of a 2-float vector (element 1 reads element 0).
+template <bool Q16> struct QRaw { typedef f32x4 type; };
+template <> struct QRaw<true> { typedef u32x2 type; };
+template <bool Q16> __device__ __forceinline__ typename QRaw<Q16>::type ldq_raw(const AttnParams& p, const float* elem_ptr) {
+    if constexpr (Q16) return *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(p.qkv) + (elem_ptr - p.qkv));
+    else return *reinterpret_cast<const f32x4*>(elem_ptr);
+}
+__device__ __forceinline__ f32x4 qcv(f32x4 raw) { return raw; }
+__device__ __forceinline__ f32x4 qcv(u32x2 raw) {
+    return f32x4{__builtin_bit_cast(float, raw[0] << 16), __builtin_bit_cast(float, raw[0] & 0xffff0000u),
+                 __builtin_bit_cast(float, raw[1] << 16), __builtin_bit_cast(float, raw[1] & 0xffff0000u)};
+}
+template <bool Q16> __device__ __forceinline__ f32x4 ldq(const AttnParams& p, const float* elem_ptr) { return qcv(ldq_raw<Q16>(p, elem_ptr)); }
+template <bool Q16> __device__ __forceinline__ void stdq(const AttnParams& p, float* elem_ptr, f32x4 v) {
+    if constexpr (Q16) *reinterpret_cast<attn_bf16x4*>(reinterpret_cast<__bf16*>(p.dqkv) + (elem_ptr - p.dqkv)) = __builtin_convertvector(v, attn_bf16x4);
+    else *reinterpret_cast<f32x4*>(elem_ptr) = v;
+}
 
 struct WgInfo {
     int bi, b, win, g, N, ih, iw;
@@ -176,7 +201,7 @@ __device__ __forceinline__ void lepe_wgrad_taps(const AttnBranch& br, const floa
 // QS = 2: the query tiles of a (window, head) are split over two workgroups (each stages the whole K / V stripe): with
 // 384 units on 256 CUs half the CUs would otherwise carry two whole units and set the kernel time; 768 half-units are
 // three per CU.  The two halves are `units` apart in the grid, i.e. on the same XCD / L2 when units % 8 == 0.
-template <int NT, int QS>
+template <int NT, int QS, bool Q16>
 __global__ __launch_bounds__(64 * (QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8))) void attn_fwd_kernel(AttnParams p, int units) {
     constexpr int NP = 16 * NT;
     constexpr int NW = QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8);
@@ -200,28 +225,28 @@ __global__ __launch_bounds__(64 * (QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8))) 
 
     ATTN_STAMP(0);
     // this wave's first query tile: issue its Q loads first so their latency overlaps the K/V staging below
-    f32x4 q0_pre = {0.f, 0.f, 0.f, 0.f}, q1_pre = q0_pre;
+    typename QRaw<Q16>::type q0_pre = {}, q1_pre = {};      // raw (see ldq_raw)
     int lq_pre = 0;
     {
         const int tq = 16 * qt0 + li;
         if (qt0 < NT && tq < N) lq_pre = token_of(br, w, p.reso, tq);
         if (qt0 < NT && tq < N && 8 * kq < p.hd) {
             const float* src = qkv_b + (long)lq_pre * C3 + ch0 + 8 * kq;
-            q0_pre = *reinterpret_cast<const f32x4*>(src);
-            q1_pre = *reinterpret_cast<const f32x4*>(src + 4);
+            q0_pre = ldq_raw<Q16>(p, src);
+            q1_pre = ldq_raw<Q16>(p, src + 4);
         }
     }
 
     for (int idx = tid; idx < NP * 8; idx += 64 * NW) {
         const int row = idx >> 3, c4 = idx & 7;
-        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+        typename QRaw<Q16>::type kv = {}, vv = {};
         if (row < N && 4 * c4 < p.hd) {
             const float* src = qkv_b + (long)token_of(br, w, p.reso, row) * C3 + ch0 + 4 * c4;
-            kv = *reinterpret_cast<const f32x4*>(src + p.C);
-            vv = *reinterpret_cast<const f32x4*>(src + 2 * p.C);
+            kv = ldq_raw<Q16>(p, src + p.C);
+            vv = ldq_raw<Q16>(p, src + 2 * p.C);
         }
-        *reinterpret_cast<f32x4*>(&Ks[row * LDT + 4 * c4]) = kv;
-        *reinterpret_cast<f32x4*>(&Vs[row * LDT + 4 * c4]) = vv;
+        *reinterpret_cast<f32x4*>(&Ks[row * LDT + 4 * c4]) = qcv(kv);
+        *reinterpret_cast<f32x4*>(&Vs[row * LDT + 4 * c4]) = qcv(vv);
     }
     for (int i = tid; i < 10 * HD; i += 64 * NW) {
         const int tap = i / HD, ch = i - tap * HD;
@@ -237,17 +262,18 @@ __global__ __launch_bounds__(64 * (QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8))) 
         int lq = lq_pre;
         float qr[8];
         {
-            f32x4 q0 = q0_pre, q1 = q1_pre;
+            typename QRaw<Q16>::type q0r = q0_pre, q1r = q1_pre;
             if (qt != qt0) {                        // only when a wave owns more than one query tile (N > 128)
-                q0 = f32x4{0.f, 0.f, 0.f, 0.f};
-                q1 = q0;
+                q0r = {};
+                q1r = {};
                 lq = qvalid ? token_of(br, w, p.reso, tq) : 0;
                 if (qvalid && 8 * kq < p.hd) {
                     const float* src = qkv_b + (long)lq * C3 + ch0 + 8 * kq;
-                    q0 = *reinterpret_cast<const f32x4*>(src);
-                    q1 = *reinterpret_cast<const f32x4*>(src + 4);
+                    q0r = ldq_raw<Q16>(p, src);
+                    q1r = ldq_raw<Q16>(p, src + 4);
                 }
             }
+            const f32x4 q0 = qcv(q0r), q1 = qcv(q1r);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 qr[e] = q0[e] * p.scale;
@@ -338,7 +364,7 @@ __device__ __forceinline__ float oct_sum(float v) {
 //       are the B operands as they stand); dS -> LDS.  The S / dP products of tile qt + 1 are issued before the VALU
 //       work of tile qt.  Then dV += LePE^T(dO), dK, dV -> global.
 //   P3  K fragments -> LDS over the dead Q image; dQ^T = K^T dS^T per query tile (one per wave) -> global.
-template <int NT>
+template <int NT, bool Q16>
 __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {      // 4 waves per SIMD: <= 128 VGPRs, two workgroups per CU at NT = 7
     constexpr int NP = 16 * NT;
     constexpr int NTHREADS = 64 * NT;
@@ -372,16 +398,19 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
     const int tk = 16 * kw + li;                       // this lane's key token
     const bool kvalid = tk < N;
     const int lk = kvalid ? token_of(br, w, p.reso, tk) : 0;
-    f32x4 qv[2], vv[2], dv[2];
+    typename QRaw<Q16>::type qv[2], vv[2];
+    f32x4 dv[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int idx = tid + it * NTHREADS, row = idx >> 3, c4 = idx & 7;
-        qv[it] = vv[it] = dv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        qv[it] = {};
+        vv[it] = {};
+        dv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (row < N && 4 * c4 < p.hd) {
             const int l = token_of(br, w, p.reso, row);
             const float* src = qkv_b + (long)l * C3 + ch0 + 4 * c4;
-            qv[it] = *reinterpret_cast<const f32x4*>(src);
-            vv[it] = *reinterpret_cast<const f32x4*>(src + 2 * p.C);
+            qv[it] = ldq_raw<Q16>(p, src);
+            vv[it] = ldq_raw<Q16>(p, src + 2 * p.C);
             dv[it] = *reinterpret_cast<const f32x4*>(dy_b + (long)l * p.C + ch0 + 4 * c4);
         }
     }
@@ -407,8 +436,8 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int idx = tid + it * NTHREADS, row = idx >> 3, c4 = idx & 7;
-        *reinterpret_cast<f32x4*>(&QK[row * LDT + 4 * c4]) = qv[it];
-        *reinterpret_cast<f32x4*>(&VS[row * LDT + 4 * c4]) = vv[it];
+        *reinterpret_cast<f32x4*>(&QK[row * LDT + 4 * c4]) = qcv(qv[it]);
+        *reinterpret_cast<f32x4*>(&VS[row * LDT + 4 * c4]) = qcv(vv[it]);
         *reinterpret_cast<f32x4*>(&Ds[row * LDT + 4 * c4]) = dv[it];
     }
     __syncthreads();
@@ -495,14 +524,15 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
     // through P1 (whose accumulators would otherwise spill); the K load's latency hides behind the two barriers below
     float kf[8], vf[8];
     {
-        f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0;
+        typename QRaw<Q16>::type k0r = {}, k1r = {};
         if (kvalid && 8 * kq < p.hd) {
             const float* src = qkv_b + (long)lk * C3 + p.C + ch0 + 8 * kq;
-            k0 = *reinterpret_cast<const f32x4*>(src);
-            k1 = *reinterpret_cast<const f32x4*>(src + 4);
+            k0r = ldq_raw<Q16>(p, src);
+            k1r = ldq_raw<Q16>(p, src + 4);
         }
         const float* vp = &VS[tk * LDT + 8 * kq];
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp), v1 = *reinterpret_cast<const f32x4*>(vp + 4);
+        const f32x4 k0 = qcv(k0r), k1 = qcv(k1r);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             kf[e] = k0[e];
@@ -583,8 +613,8 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
                                    : lepe_taps4<false, -1>(br, Ds, Wl, rr, cc, tk, d0, dVt[df]);
             if (d0 < p.hd) {
                 float* dst = dqkv_b + (long)lk * C3 + ch0 + d0;
-                *reinterpret_cast<f32x4*>(dst + p.C) = dKt[df] * p.scale;
-                *reinterpret_cast<f32x4*>(dst + 2 * p.C) = acc;
+                stdq<Q16>(p, dst + p.C, dKt[df] * p.scale);
+                stdq<Q16>(p, dst + 2 * p.C, acc);
             }
         }
     }
@@ -616,8 +646,8 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
         const int tq = 16 * qt + li;
         if (tq < N) {
             float* dst = dqkv_b + (long)token_of(br, w, p.reso, tq) * C3 + ch0 + 4 * kq;
-            if (4 * kq < p.hd) *reinterpret_cast<f32x4*>(dst) = dQt[0] * p.scale;
-            if (16 + 4 * kq < p.hd) *reinterpret_cast<f32x4*>(dst + 16) = dQt[1] * p.scale;
+            if (4 * kq < p.hd) stdq<Q16>(p, dst, dQt[0] * p.scale);
+            if (16 + 4 * kq < p.hd) stdq<Q16>(p, dst + 16, dQt[1] * p.scale);
         }
     }
     ATTN_STAMP(5);
@@ -654,6 +684,7 @@ __device__ __forceinline__ int token_of2(const AttnBranch& br, int ih, int iw, i
 }
 
 // grid: ceil(B * L * heads_total / 32) blocks of 256 threads; 8 lanes per (token, head)
+template <bool Q16>
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
     const int L = p.reso * p.reso, C3 = 3 * p.C;
     const long item = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
@@ -680,7 +711,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
                 const int r2 = r + ky - 1, c2 = c + kx - 1;
                 if ((unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp) {
                     const int l2 = (ih * br.H_sp + r2) * p.reso + iw * br.W_sp + c2;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(p.qkv + ((long)b * L + l2) * C3 + 2 * p.C + ch0);
+                    const f32x4 v = ldq<Q16>(p, p.qkv + ((long)b * L + l2) * C3 + 2 * p.C + ch0);
                     const int tap = ky * 3 + kx;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) lepe[e] += br.lepe_w[(cb + e) * 9 + tap] * v[e];
@@ -700,6 +731,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
 }
 
 // one workgroup (4 waves) = 64 keys of one (branch, window, head); wave w owns keys [k0 + 16 w, +16)
+template <bool Q16>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk) {
     __shared__ __attribute__((aligned(16))) float Qc[64 * LDT];
     __shared__ __attribute__((aligned(16))) float Dc[64 * LDT];
@@ -723,8 +755,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk
     for (int e = 0; e < 8; ++e) kf[e] = vf[e] = 0.f;
     if (kvalid && 8 * kq < p.hd) {
         const float* src = qkv_b + (long)lk * C3 + ch0 + 8 * kq;
-        const f32x4 k0 = *reinterpret_cast<const f32x4*>(src + p.C), k1 = *reinterpret_cast<const f32x4*>(src + p.C + 4);
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 2 * p.C), v1 = *reinterpret_cast<const f32x4*>(src + 2 * p.C + 4);
+        const auto k0r = ldq_raw<Q16>(p, src + p.C), k1r = ldq_raw<Q16>(p, src + p.C + 4);
+        const auto v0r = ldq_raw<Q16>(p, src + 2 * p.C), v1r = ldq_raw<Q16>(p, src + 2 * p.C + 4);
+        const f32x4 k0 = qcv(k0r), k1 = qcv(k1r), v0 = qcv(v0r), v1 = qcv(v1r);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { kf[e] = k0[e]; kf[4 + e] = k1[e]; vf[e] = v0[e]; vf[4 + e] = v1[e]; }
     }
@@ -733,13 +766,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk
     for (int q0 = 0; q0 < N; q0 += 64) {
         for (int idx = tid; idx < 64 * 8; idx += 256) {
             const int row = idx >> 3, c4 = idx & 7, tq = q0 + row;
-            f32x4 qv = {0.f, 0.f, 0.f, 0.f}, dv = qv;
+            typename QRaw<Q16>::type qv = {};
+            f32x4 dv = {0.f, 0.f, 0.f, 0.f};
             if (tq < N && 4 * c4 < p.hd) {
                 const int l = token_of2(br, w.ih, w.iw, p.reso, tq);
-                qv = *reinterpret_cast<const f32x4*>(qkv_b + (long)l * C3 + ch0 + 4 * c4);
+                qv = ldq_raw<Q16>(p, qkv_b + (long)l * C3 + ch0 + 4 * c4);
                 dv = *reinterpret_cast<const f32x4*>(dy_b + (long)l * p.C + ch0 + 4 * c4);
             }
-            *reinterpret_cast<f32x4*>(&Qc[row * LDT + 4 * c4]) = qv;
+            *reinterpret_cast<f32x4*>(&Qc[row * LDT + 4 * c4]) = qcv(qv);
             *reinterpret_cast<f32x4*>(&Dc[row * LDT + 4 * c4]) = dv;
         }
         if (tid < 128) {
@@ -802,14 +836,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk
                 }
             float* dst = dqkv_b + (long)lk * C3 + ch0 + d0;
             if (d0 < p.hd) {
-                *reinterpret_cast<f32x4*>(dst + p.C) = dKt[df] * p.scale;
-                *reinterpret_cast<f32x4*>(dst + 2 * p.C) = acc;
+                stdq<Q16>(p, dst + p.C, dKt[df] * p.scale);
+                stdq<Q16>(p, dst + 2 * p.C, acc);
             }
         }
     }
 }
 
 // one workgroup (4 waves) = 64 queries of one (branch, window, head); wave w owns queries [q0 + 16 w, +16)
+template <bool Q16>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk) {
     __shared__ __attribute__((aligned(16))) float Kc[64 * LDT];
     __shared__ __attribute__((aligned(16))) float Vc[64 * LDT];
@@ -836,9 +871,10 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk)
     }
     if (qvalid && 8 * kq < p.hd) {
         const float* src = qkv_b + (long)lq * C3 + ch0 + 8 * kq;
-        const f32x4 q0 = *reinterpret_cast<const f32x4*>(src), q1 = *reinterpret_cast<const f32x4*>(src + 4);
+        const auto q0r = ldq_raw<Q16>(p, src), q1r = ldq_raw<Q16>(p, src + 4);
         const float* dsrc = dy_b + (long)lq * p.C + ch0 + 8 * kq;
         const f32x4 d0 = *reinterpret_cast<const f32x4*>(dsrc), d1 = *reinterpret_cast<const f32x4*>(dsrc + 4);
+        const f32x4 q0 = qcv(q0r), q1 = qcv(q1r);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { qr[e] = q0[e] * p.scale; qr[4 + e] = q1[e] * p.scale; dor[e] = d0[e]; dor[4 + e] = d1[e]; }
     }
@@ -846,14 +882,14 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk)
     for (int k0 = 0; k0 < N; k0 += 64) {
         for (int idx = tid; idx < 64 * 8; idx += 256) {
             const int row = idx >> 3, c4 = idx & 7, tk = k0 + row;
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+            typename QRaw<Q16>::type kv = {}, vv = {};
             if (tk < N && 4 * c4 < p.hd) {
                 const float* src = qkv_b + (long)token_of2(br, w.ih, w.iw, p.reso, tk) * C3 + ch0 + 4 * c4;
-                kv = *reinterpret_cast<const f32x4*>(src + p.C);
-                vv = *reinterpret_cast<const f32x4*>(src + 2 * p.C);
+                kv = ldq_raw<Q16>(p, src + p.C);
+                vv = ldq_raw<Q16>(p, src + 2 * p.C);
             }
-            *reinterpret_cast<f32x4*>(&Kc[row * LDT + 4 * c4]) = kv;
-            *reinterpret_cast<f32x4*>(&Vc[row * LDT + 4 * c4]) = vv;
+            *reinterpret_cast<f32x4*>(&Kc[row * LDT + 4 * c4]) = qcv(kv);
+            *reinterpret_cast<f32x4*>(&Vc[row * LDT + 4 * c4]) = qcv(vv);
         }
         __syncthreads();
 #pragma unroll
@@ -880,8 +916,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk)
     }
     if (qvalid) {
         float* dst = dqkv_b + (long)lq * C3 + ch0 + 4 * kq;
-        if (4 * kq < p.hd) *reinterpret_cast<f32x4*>(dst) = dQt[0] * p.scale;
-        if (16 + 4 * kq < p.hd) *reinterpret_cast<f32x4*>(dst + 16) = dQt[1] * p.scale;
+        if (4 * kq < p.hd) stdq<Q16>(p, dst, dQt[0] * p.scale);
+        if (16 + 4 * kq < p.hd) stdq<Q16>(p, dst + 16, dQt[1] * p.scale);
     }
 }
 
@@ -892,6 +928,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk)
 // only (L1 / L2 resident).  (The first version -- one thread per (token slot, channel), scalar loads -- took 69 us per launch
 // at 384 x 384, 8 % of that step.)
 constexpr int LW_SUB = 4;
+template <bool Q16>
 __global__ __launch_bounds__(256) void lepe_wgrad_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) float red[16 * 8 * 4];
     const int sub = (int)blockIdx.x % LW_SUB;
@@ -918,7 +955,7 @@ __global__ __launch_bounds__(256) void lepe_wgrad_kernel(AttnParams p) {
             } else {
                 const int r2 = rr + ky - 1, c2 = cc + kx - 1;
                 if ((unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp)
-                    acc += g4 * *reinterpret_cast<const f32x4*>(v_b + (long)token_of(br, w, p.reso, r2 * br.W_sp + c2) * C3);
+                    acc += g4 * ldq<Q16>(p, v_b + (long)token_of(br, w, p.reso, r2 * br.W_sp + c2) * C3);
             }
         }
     }
@@ -1009,8 +1046,8 @@ int fill_params(AttnParams& p, const char* who, int B, int reso, int C, int nbra
     return CSWIN_OK;
 }
 
-template <int NT>
-int launch_fwd(const AttnParams& p, int nwg, hipStream_t st) {
+template <int NT, bool Q16>
+int launch_fwd_q(const AttnParams& p, int nwg, hipStream_t st) {
     constexpr int NW = NT < 8 ? NT : 8;
     const size_t lds = (size_t)(2 * 16 * NT * LDT + 10 * HD) * sizeof(float);
     if (lds > 64 * 1024) {
@@ -1018,7 +1055,7 @@ int launch_fwd(const AttnParams& p, int nwg, hipStream_t st) {
         // stream operation: it stays out of graph captures); the size is a constant of the template
         static std::once_flag once;
         static hipError_t status = hipSuccess;
-        std::call_once(once, [&] { status = hipFuncSetAttribute((const void*)attn_fwd_kernel<NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+        std::call_once(once, [&] { status = hipFuncSetAttribute((const void*)attn_fwd_kernel<NT, 1, Q16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
         if (status != hipSuccess) { cswin_set_error("attn_fwd: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(status)); return CSWIN_ERR_HIP; }
     }
     if constexpr (NT <= 8) {
@@ -1026,12 +1063,17 @@ int launch_fwd(const AttnParams& p, int nwg, hipStream_t st) {
         static const char* force = getenv("CSWIN_ATTN_FWD_QSPLIT");                      // tuning aid: "1" or "2"
         const bool split = force ? force[0] == '2' : (nwg < 1024 && nwg % 256 != 0 && NT >= 6);   // measured: pays at N = 98, not at N = 49
         if (split) {
-            hipLaunchKernelGGL((attn_fwd_kernel<NT, 2>), dim3(2 * nwg), dim3(64 * ((NT + 1) / 2)), lds, st, p, nwg);
+            hipLaunchKernelGGL((attn_fwd_kernel<NT, 2, Q16>), dim3(2 * nwg), dim3(64 * ((NT + 1) / 2)), lds, st, p, nwg);
             return CSWIN_OK;
         }
     }
-    hipLaunchKernelGGL((attn_fwd_kernel<NT, 1>), dim3(nwg), dim3(64 * NW), lds, st, p, nwg);
+    hipLaunchKernelGGL((attn_fwd_kernel<NT, 1, Q16>), dim3(nwg), dim3(64 * NW), lds, st, p, nwg);
     return CSWIN_OK;
+}
+
+template <int NT>
+int launch_fwd(const AttnParams& p, int nwg, hipStream_t st) {
+    return p.qkv_bf16 ? launch_fwd_q<NT, true>(p, nwg, st) : launch_fwd_q<NT, false>(p, nwg, st);
 }
 
 inline int ds_stride_for(int N) {            // smallest stride >= N with stride = 4 (mod 8): 16-B aligned rows, and the four
@@ -1040,8 +1082,8 @@ inline int ds_stride_for(int N) {            // smallest stride >= N with stride
     return s;
 }
 
-template <int NT>
-int launch_bwd2(const AttnParams& p, int nwg, hipStream_t st) {
+template <int NT, bool Q16>
+int launch_bwd2_q(const AttnParams& p, int nwg, hipStream_t st) {
     constexpr int NP = 16 * NT;
     const int S = p.ds_stride;
     const int vs_min = NP * LDT + NT * 10 * HD;
@@ -1052,11 +1094,24 @@ int launch_bwd2(const AttnParams& p, int nwg, hipStream_t st) {
         static hipError_t status = hipSuccess;
         constexpr int SMAX = ((NP + 3) / 4 * 4) + 8;
         constexpr size_t lds_max = (size_t)(2 * NP * LDT + NP * SMAX + 2 * NP + 10 * HD) * sizeof(float);
-        std::call_once(once, [&] { status = hipFuncSetAttribute((const void*)attn_bwd2_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); });
+        std::call_once(once, [&] { status = hipFuncSetAttribute((const void*)attn_bwd2_kernel<NT, Q16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); });
         if (status != hipSuccess) { cswin_set_error("attn_bwd: cannot reserve %zu B LDS: %s", lds_max, hipGetErrorString(status)); return CSWIN_ERR_HIP; }
     }
-    hipLaunchKernelGGL((attn_bwd2_kernel<NT>), dim3(nwg), dim3(64 * NT), lds, st, p);
+    hipLaunchKernelGGL((attn_bwd2_kernel<NT, Q16>), dim3(nwg), dim3(64 * NT), lds, st, p);
     return CSWIN_OK;
+}
+
+template <int NT>
+int launch_bwd2(const AttnParams& p, int nwg, hipStream_t st) {
+    return p.qkv_bf16 ? launch_bwd2_q<NT, true>(p, nwg, st) : launch_bwd2_q<NT, false>(p, nwg, st);
+}
+
+template <bool Q16>
+void launch_bwd_two_pass(const AttnParams& p, long items, int nwg, int nblk, hipStream_t st) {
+    hipLaunchKernelGGL(attn_delta_kernel<Q16>, dim3((unsigned)((items * 8 + 255) / 256)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(attn_bwd_kv_kernel<Q16>, dim3(nwg * nblk), dim3(256), 0, st, p, nblk);
+    hipLaunchKernelGGL(attn_bwd_q_kernel<Q16>, dim3(nwg * nblk), dim3(256), 0, st, p, nblk);
+    hipLaunchKernelGGL(lepe_wgrad_kernel<Q16>, dim3(nwg * LW_SUB), dim3(256), 0, st, p);
 }
 
 long long* g_attn_stamps = nullptr;     // debug only (cswin_debug_set_attn_stamps)
@@ -1076,8 +1131,10 @@ void cswin_debug_set_attn_stamps(void* p) { g_attn_stamps = (long long*)p; }
 // qkv (B, L, 3C) -> y (B, L, C), lse (B, heads_total, L).  nbranch = 2: branch i uses channels
 // [i*C/2, (i+1)*C/2) with stripe mode idx[i]; nbranch = 1: whole C, idx[0] (normally -1).
 int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, float* y, float* lse,
-                   int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split, float scale, void* stream) {
+                   int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split, float scale, int qkv_bf16,
+                   void* stream) {
     AttnParams p = {};
+    p.qkv_bf16 = qkv_bf16 != 0;
     int nt, nwg;
     int rc = fill_params(p, "attn_fwd", B, reso, C, nbranch, heads, idx, split, scale, &nt, &nwg);
     if (rc) return rc;
@@ -1117,8 +1174,9 @@ size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* 
 int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, const float* lse,
                    const float* y, const float* dy, float* dqkv, float* const* dlepe_w, float* const* dlepe_b,
                    void* workspace, size_t ws_bytes, int B, int reso, int C, int nbranch, const int* heads, const int* idx,
-                   int split, float scale, cswin_reduce_job* deferred, void* stream) {
+                   int split, float scale, cswin_reduce_job* deferred, int qkv_bf16, void* stream) {
     AttnParams p = {};
+    p.qkv_bf16 = qkv_bf16 != 0;
     int nt, nwg;
     int rc = fill_params(p, "attn_bwd", B, reso, C, nbranch, heads, idx, split, scale, &nt, &nwg);
     if (rc) return rc;
@@ -1142,10 +1200,8 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
         // windows of more than 112 tokens (384x384: N = 144, 288): two-pass path
         const int N = p.br[0].H_sp * p.br[0].W_sp, nblk = (N + 63) / 64;
         const long items = (long)B * p.heads_total * reso * reso;
-        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items * 8 + 255) / 256)), dim3(256), 0, st, p);
-        hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(nwg * nblk), dim3(256), 0, st, p, nblk);
-        hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(nwg * nblk), dim3(256), 0, st, p, nblk);
-        hipLaunchKernelGGL(lepe_wgrad_kernel, dim3(nwg * LW_SUB), dim3(256), 0, st, p);
+        if (p.qkv_bf16) launch_bwd_two_pass<true>(p, items, nwg, nblk, st);
+        else launch_bwd_two_pass<false>(p, items, nwg, nblk, st);
         rc = CSWIN_OK;
     } else {
         switch (nt) {

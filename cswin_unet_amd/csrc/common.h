@@ -6,6 +6,7 @@
 #include <stdio.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CSWIN_OK 0
@@ -187,6 +188,7 @@ typedef struct cswin_wgrad_desc {
     size_t ws_bytes;
     int rows_per_sample, M, N, K;
     int precision;           /* 0 = exact fp32 MFMA, 1 = bf16 operands (all problems of one launch agree) */
+    int io_bf16;             /* precision 1 only: bit 0 = dy is stored as bf16, bit 1 = x is stored as bf16 */
 } cswin_wgrad_desc;
 }
 

@@ -20,6 +20,7 @@
 // and cover each other's barriers).
 #include <stdlib.h>
 
+#include <type_traits>
 #include "common.h"
 #include "gemm_epilogue.h"
 
@@ -46,6 +47,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 struct PlainSrc {
     const float* p; long ld; int rows, cols;
     const float* row_scale; int rows_per_sample;     // optional per-row multiplier (DropPath backward)
+    int bf16;                                        // the matrix is stored as bf16 (p is then only an element-indexed handle)
     struct Row { const float* base; float s; };
     __device__ Row row(int i) const {
         Row r;
@@ -55,6 +57,16 @@ struct PlainSrc {
     }
     __device__ const float* ptr(const Row& r, int j) const { return (r.base && j < cols) ? r.base + j : nullptr; }
 };
+
+// bf16 STORAGE of an operand (activations of the bf16 mode): only plain matrices; every source computes addresses in elements,
+// so the element offset of the fp32-typed pointer is re-applied to the bf16 base.
+template <class S> __device__ __forceinline__ bool src_is_bf16(const S&) { return false; }
+__device__ __forceinline__ bool src_is_bf16(const PlainSrc& s) { return s.bf16 != 0; }
+// 4 bf16 as two raw dwords (an INTEGER vector: see widen_bf16x4); they go to the LDS image as they are (stash below)
+template <class S> __device__ __forceinline__ u32x2 src_load4_bf16(const S&, const float*) { return u32x2{0u, 0u}; }
+__device__ __forceinline__ u32x2 src_load4_bf16(const PlainSrc& s, const float* p) {
+    return *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(s.p) + (p - s.p));
+}
 
 // cat([p0 (c0 cols), p1 (cols - c0)], dim=-1) without materialising it (skip-concat, cswin_unet.py:509-510)
 struct ConcatSrc {
@@ -240,8 +252,11 @@ __device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Ep
     // register prefetch of the next tile: raw loads only -- nothing may consume pa/pb before stash(), or the
     // compiler waits for the loads in front of the MFMA section
     f32x4 pa[QA], pb[QB];
+    u32x2 pa16[QA];                                  // A stored as bf16: its raw chunks (pa is then unused)
     float pas[QA];
-    auto fetch = [&](int r0) {
+    // a16 (std::true_type / false_type): A is STORED as bf16.  A compile-time copy of the main loop per storage type: a run-time
+    // choice between the 8-B and the 16-B load inside fetch() splits it into basic blocks and the loads end up waiting for one another.
+    auto fetch = [&](int r0, auto a16) {
 #pragma unroll
         for (int q = 0; q < QA; ++q) {
             typename ASrc::Row rr;
@@ -257,8 +272,13 @@ __device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Ep
             if (SCALE_A) pas[q] = rr.s;
             if (VEC == 4) {
                 const float* p = (!A_RC || j < r_end) ? A.ptr(rr, j) : nullptr;
-                pa[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (p) pa[q] = *reinterpret_cast<const f32x4*>(p);
+                if constexpr (decltype(a16)::value) {
+                    pa16[q] = u32x2{0u, 0u};
+                    if (p) pa16[q] = src_load4_bf16(A, p);
+                } else {
+                    pa[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (p) pa[q] = *reinterpret_cast<const f32x4*>(p);
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -292,20 +312,38 @@ __device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Ep
             }
         }
     };
-    auto stash = [&]() {
+    auto stash = [&](auto a16) {
 #pragma unroll
         for (int q = 0; q < QA; ++q) {
-            f32x4 v = pa[q];
-            if (SCALE_A) v *= pas[q];
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (!decltype(a16)::value) v = pa[q];
             if constexpr (PREC == 1) {
+                // the 4 bf16 of this chunk as two packed dwords (plain integers: hipcc 7.2 miscompiles element extraction from a
+                // bf16 vector that is merged from two branches -- all four stores received element 0)
+                unsigned h01, h23;
+                if constexpr (decltype(a16)::value) {    // stored as bf16: the bits go to the image unchanged
+                    h01 = pa16[q][0];
+                    h23 = pa16[q][1];
+                    if (SCALE_A) {
+                        const u32x2 u = __builtin_bit_cast(u32x2, __builtin_convertvector(widen_bf16x4(pa16[q]) * pas[q], bf16x4));
+                        h01 = u[0]; h23 = u[1];
+                    }
+                } else {
+                    if (SCALE_A) v *= pas[q];
+                    const u32x2 u = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
+                    h01 = u[0]; h23 = u[1];
+                }
                 if (A_RC) {
-                    *reinterpret_cast<bf16x4*>(&As16[(a_r + q * A_RPP) * LD16 + 4 * a_c]) = __builtin_convertvector(v, bf16x4);
+                    *reinterpret_cast<u32x2*>(&As16[(a_r + q * A_RPP) * LD16 + 4 * a_c]) = u32x2{h01, h23};
                 } else {                                 // source is row(m)-contiguous: transpose into the [m][r] image
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        As16[(4 * a_c + e) * LD16 + a_r + q * A_RPP] = __builtin_bit_cast(unsigned short, (__bf16)v[e]);
+                    unsigned short* col = &As16[4 * a_c * LD16 + a_r + q * A_RPP];
+                    col[0] = (unsigned short)(h01 & 0xffffu);
+                    col[LD16] = (unsigned short)(h01 >> 16);
+                    col[2 * LD16] = (unsigned short)(h23 & 0xffffu);
+                    col[3 * LD16] = (unsigned short)(h23 >> 16);
                 }
             } else {
+                if (SCALE_A) v *= pas[q];
                 *reinterpret_cast<f32x4*>(&As[(a_r + q * A_RPP) * LDA + 4 * a_c]) = v;
             }
         }
@@ -342,14 +380,14 @@ __device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Ep
     const bool do_colsum = !A_RC && epi.colsum && n0 == 0 && tid < BM;
 
     if (epi.stamps && tid == 0) { epi.stamps[8L * stamp_row + 0] = __builtin_amdgcn_s_memtime(); epi.stamps[8L * stamp_row + 4] = __builtin_amdgcn_s_getreg(6164); epi.stamps[8L * stamp_row + 5] = __builtin_amdgcn_s_memrealtime(); }
-    if (r_begin < r_end) {
-        fetch(r_begin);
-        stash();
+    auto main_loop = [&](auto a16) {
+        fetch(r_begin, a16);
+        stash(a16);
         __syncthreads();
         if (epi.stamps && tid == 0) epi.stamps[8L * stamp_row + 1] = __builtin_amdgcn_s_memtime();
         for (int r0 = r_begin; r0 < r_end; r0 += BK) {
             const bool more = r0 + BK < r_end;
-            if (more) fetch(r0 + BK);
+            if (more) fetch(r0 + BK, a16);
             if (do_colsum) {
                 if constexpr (PREC == 1) {
 #pragma unroll 8
@@ -425,9 +463,17 @@ __device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Ep
             }
             __syncthreads();
             if (more) {
-                stash();
+                stash(a16);
                 __syncthreads();
             }
+        }
+    };
+    if (r_begin < r_end) {
+        if constexpr (PREC == 1 && A_RC && VEC == 4 && std::is_same<ASrc, PlainSrc>::value) {
+            if (src_is_bf16(A)) main_loop(std::true_type{});
+            else main_loop(std::false_type{});
+        } else {
+            main_loop(std::false_type{});
         }
     }
 
@@ -463,7 +509,12 @@ __device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Ep
     }
     Epilogue e = epi;
     e.C += (long)split * e.split_stride;
-    run_epilogue<EPI, FM, FN>(e, acc, M, N, m0 + wm0, n0 + wn0, lane, lds + wave * EP_WAVE_FLOATS, e.vec_store != 0);
+    if constexpr (EPI == EPI_GELUBWD) {
+        if (e.pre_bf16) run_epilogue<EPI, FM, FN, true>(e, acc, M, N, m0 + wm0, n0 + wn0, lane, lds + wave * EP_WAVE_FLOATS, e.vec_store != 0);
+        else run_epilogue<EPI, FM, FN, false>(e, acc, M, N, m0 + wm0, n0 + wn0, lane, lds + wave * EP_WAVE_FLOATS, e.vec_store != 0);
+    } else {
+        run_epilogue<EPI, FM, FN>(e, acc, M, N, m0 + wm0, n0 + wn0, lane, lds + wave * EP_WAVE_FLOATS, e.vec_store != 0);
+    }
     if (epi.stamps && tid == 0) { epi.stamps[8L * stamp_row + 3] = __builtin_amdgcn_s_memtime(); epi.stamps[8L * stamp_row + 6] = __builtin_amdgcn_s_memrealtime(); }
     if (do_colsum && m0 + tid < M) epi.colsum[(long)split * epi.colsum_stride + m0 + tid] = csum;
 }
@@ -609,8 +660,10 @@ void cswin_debug_set_stamps(void* p) { g_stamps = (long long*)p; }
 
 int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* w, const float* bias, float* y,
                      float* y_act, const float* residual, const float* row_scale, int rows_per_sample, int M, int N,
-                     int K, int precision, void* stream) {
+                     int K, int precision, int io_bf16, void* stream) {
     CSWIN_CHECK_PRECISION(precision, "linear_fwd");
+    CSWIN_REQUIRE(io_bf16 == 0 || (precision == 1 && !x2 && (io_bf16 & ~3) == 0 && K % 4 == 0 && N % 4 == 0 && !((io_bf16 & 2) && residual)), CSWIN_ERR_UNSUPPORTED,
+                  "linear_fwd: bf16 storage (io_bf16 = %d: 1 = x, 2 = y / y_act) needs precision 1, a plain input, K and N multiples of 4; a residual output stays fp32", io_bf16);
     CSWIN_REQUIRE(x && w && y && M > 0 && N > 0 && K > 0, CSWIN_ERR_SHAPE, "linear_fwd: bad arguments M=%d N=%d K=%d", M, N, K);
     CSWIN_REQUIRE(!x2 || (k_split > 0 && k_split < K), CSWIN_ERR_SHAPE, "linear_fwd: bad concat split %d of K=%d", k_split, K);
     CSWIN_REQUIRE(!row_scale || rows_per_sample > 0, CSWIN_ERR_SHAPE, "linear_fwd: rows_per_sample must be > 0");
@@ -620,6 +673,7 @@ int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* 
     e.Cact = y_act; e.ldact = N;
     e.residual = residual; e.ldres = N;
     e.row_scale = row_scale; e.rows_per_sample = rows_per_sample;
+    e.c_bf16 = (io_bf16 & 2) != 0;
     PlainSrc B = {w, K, N, K, nullptr, 1};
     CSWIN_REQUIRE(!(y_act && residual), CSWIN_ERR_UNSUPPORTED, "linear_fwd: activation and residual epilogues are exclusive");
     const int rk = cdiv(K, BKMAX) * BKMAX;
@@ -643,8 +697,10 @@ int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* 
                 return CSWIN_OK;
             }
         }
-        PlainSrc A = {x, K, M, K, nullptr, 1};
+        PlainSrc A = {x, K, M, K, nullptr, 1, io_bf16 & 1};
         bool vec = (K % 4 == 0) && aligned16(x) && aligned16(w);
+        CSWIN_REQUIRE(io_bf16 == 0 || (vec && aligned16(y) && (!y_act || aligned16(y_act)) && (!bias || aligned16(bias))), CSWIN_ERR_ALIGN,
+                      "linear_fwd: bf16 storage needs 16-B aligned operands");
         if (y_act) {
             if (vec) launch_gemm<true, true, 4, EPI_ACT, false>(A, B, e, M, N, K, 1, rk, precision, st);
             else launch_gemm<true, true, 1, EPI_ACT, false>(A, B, e, M, N, K, 1, rk, precision, st);
@@ -663,8 +719,10 @@ int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* 
 // dx[M,K] = (row_scale . dy)[M,N] @ w[N,K]   (optionally * gelu'(gelu_pre), + add; optionally split into dx | dx2)
 int cswin_linear_bwd_data(const float* dy, const float* w, float* dx, float* dx2, int k_split, const float* gelu_pre,
                           const float* row_scale, int rows_per_sample, const float* add, int M, int N, int K,
-                          int precision, void* stream) {
+                          int precision, int io_bf16, void* stream) {
     CSWIN_CHECK_PRECISION(precision, "linear_bwd_data");
+    CSWIN_REQUIRE(io_bf16 == 0 || (precision == 1 && !dx2 && !add && (io_bf16 & ~11) == 0 && K % 4 == 0 && N % 4 == 0), CSWIN_ERR_UNSUPPORTED,
+                  "linear_bwd_data: bf16 storage (io_bf16 = %d: 1 = dy, 2 = dx, 8 = gelu_pre) needs precision 1, no split / add, K and N multiples of 4", io_bf16);
     CSWIN_REQUIRE(dy && w && dx && M > 0 && N > 0 && K > 0, CSWIN_ERR_SHAPE, "linear_bwd_data: bad arguments");
     CSWIN_REQUIRE(!dx2 || (k_split > 0 && k_split < K), CSWIN_ERR_SHAPE, "linear_bwd_data: bad concat split");
     CSWIN_REQUIRE(!row_scale || rows_per_sample > 0, CSWIN_ERR_SHAPE, "linear_bwd_data: rows_per_sample must be > 0");
@@ -674,7 +732,11 @@ int cswin_linear_bwd_data(const float* dy, const float* w, float* dx, float* dx2
     e.gelu_pre = gelu_pre; e.ldpre = K;
     e.row_scale = row_scale; e.rows_per_sample = rows_per_sample;
     e.residual = add; e.ldres = K;
-    PlainSrc A = {dy, N, M, N, nullptr, 1};
+    e.c_bf16 = (io_bf16 & 2) != 0;
+    e.pre_bf16 = (io_bf16 & 8) != 0;
+    CSWIN_REQUIRE(io_bf16 == 0 || (aligned16(dy) && aligned16(w) && aligned16(dx) && (!gelu_pre || aligned16(gelu_pre))), CSWIN_ERR_ALIGN,
+                  "linear_bwd_data: bf16 storage needs 16-B aligned operands");
+    PlainSrc A = {dy, N, M, N, nullptr, 1, io_bf16 & 1};
     PlainSrc B = {w, K, N, K, nullptr, 1};     // S(i = n (reduction), j = k): row-contiguous image
     bool vec = (N % 4 == 0) && (K % 4 == 0) && aligned16(dy) && aligned16(w);
     // output rows = M, output cols = K, reduction = N
@@ -729,7 +791,7 @@ int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, in
     hipStream_t st = (hipStream_t)stream;
     if (precision == 1 && !x2 && N % 4 == 0 && K % 4 == 0 && aligned16(dy) && aligned16(x) && aligned16(workspace)) {
         // bf16 mode: the transposing-read kernel (wgrad16.hip) through the batch entry, as a batch of one
-        cswin_wgrad_desc d1 = {dy, x, row_scale, dw, dbias, workspace, ws_bytes, rows_per_sample, M, N, K, 1};
+        cswin_wgrad_desc d1 = {dy, x, row_scale, dw, dbias, workspace, ws_bytes, rows_per_sample, M, N, K, 1, 0};
         cswin_reduce_job job;
         int rc = cswin_linear_bwd_weight_batch(&d1, 1, &job, stream);
         if (rc) return rc;
@@ -781,6 +843,7 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
     CSWIN_CHECK_PRECISION(precision, "linear_bwd_weight_batch");
     for (int i = 0; i < n; ++i) {
         CSWIN_REQUIRE(d[i].precision == precision, CSWIN_ERR_UNSUPPORTED, "linear_bwd_weight_batch: problems of one launch share one precision");
+        CSWIN_REQUIRE(d[i].io_bf16 == 0 || (precision == 1 && (d[i].io_bf16 & ~3) == 0), CSWIN_ERR_UNSUPPORTED, "linear_bwd_weight_batch: bf16 storage needs precision 1");
         CSWIN_REQUIRE(d[i].dy && d[i].x && d[i].dw && d[i].M > 0 && d[i].N > 0 && d[i].K > 0, CSWIN_ERR_SHAPE, "linear_bwd_weight_batch: bad problem %d", i);
         CSWIN_REQUIRE(!d[i].row_scale || d[i].rows_per_sample > 0, CSWIN_ERR_SHAPE, "linear_bwd_weight_batch: rows_per_sample must be > 0");
         size_t need = cswin_linear_bwd_weight_workspace(d[i].M, d[i].N, d[i].K);
@@ -788,6 +851,7 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
         fast = fast && d[i].N % 4 == 0 && d[i].K % 4 == 0 && aligned16(d[i].dy) && aligned16(d[i].x) && aligned16(d[i].workspace);
     }
     if (!fast) {
+        for (int i = 0; i < n; ++i) CSWIN_REQUIRE(d[i].io_bf16 == 0, CSWIN_ERR_ALIGN, "linear_bwd_weight_batch: bf16 storage needs N, K multiples of 4 and 16-B alignment");
         for (int i = 0; i < n; ++i) {
             int rc = cswin_linear_bwd_weight(d[i].dy, d[i].x, nullptr, 0, d[i].row_scale, d[i].rows_per_sample, d[i].dw, d[i].dbias,
                                              d[i].workspace, d[i].ws_bytes, d[i].M, d[i].N, d[i].K, &deferred[i], precision, stream);
@@ -796,7 +860,7 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
         return CSWIN_OK;
     }
     static const int w16_off = getenv("CSWIN_WGRAD16") ? atoi(getenv("CSWIN_WGRAD16")) == 0 : 0;     // tuning aid
-    if (precision == 1 && !w16_off) {
+    if (precision == 1 && (!w16_off || d[0].io_bf16 || (n > 1 && d[1].io_bf16) || (n > 2 && d[2].io_bf16) || (n > 3 && d[3].io_bf16))) {
         // bf16 operands: 128 x 128 tiles, ~3 workgroups per CU over the whole batch (load-bound: see wgrad16.hip)
         int splits[WGRAD_BATCH], rps[WGRAD_BATCH];
         for (int i = 0; i < n; ++i) {

@@ -4,6 +4,18 @@
 
 namespace {
 
+typedef __bf16 epi_bf16x4 __attribute__((ext_vector_type(4)));
+// widen 4 bf16 held as two raw dwords.  Raw bf16 bits travel in INTEGER vectors: hipcc 7.2 miscompiles bit casts of the
+// elements of a 2-float vector (element 1 reads element 0).
+__device__ __forceinline__ f32x4 widen_bf16x4(u32x2 raw) {
+    return f32x4{__builtin_bit_cast(float, raw[0] << 16), __builtin_bit_cast(float, raw[0] & 0xffff0000u),
+                 __builtin_bit_cast(float, raw[1] << 16), __builtin_bit_cast(float, raw[1] & 0xffff0000u)};
+}
+__device__ __forceinline__ void epi_store4(float* base, long idx, f32x4 v, int bf16) {
+    if (bf16) *reinterpret_cast<epi_bf16x4*>(reinterpret_cast<__bf16*>(base) + idx) = __builtin_convertvector(v, epi_bf16x4);
+    else *reinterpret_cast<f32x4*>(base + idx) = v;
+}
+
 // ------------------------------------------------------------------------------------
 // epilogue
 // ------------------------------------------------------------------------------------
@@ -21,6 +33,8 @@ struct Epilogue {
     float* colsum; int colsum_stride;         // TN only: partial column sums of A (dbias), [split][M]
     int rm_on, rm_H, rm_W, rm_H2, rm_W2, rm_py, rm_px;   // output row m is a parity-class pixel index -> full (b, iy, ix) row
     int vec_store;                            // 1: every output / auxiliary row is 16-B aligned and N % 4 == 0
+    int c_bf16;                               // C and Cact are stored as bf16 (vector path only; bf16 activation storage)
+    int pre_bf16;                             // gelu_pre is stored as bf16
     long long* stamps;                        // debug: per-workgroup s_memtime stamps [nblk][8] (NULL in production)
 };
 
@@ -32,7 +46,9 @@ struct Epilogue {
 constexpr int EP_LD = 36;
 constexpr int EP_WAVE_FLOATS = 32 * EP_LD;
 
-template <int EPI, int FM, int FN>
+// PRE16: gelu_pre is stored as bf16 (EPI_GELUBWD) -- compile-time, so that the four auxiliary loads of a fragment stay in one
+// basic block and are issued back to back.
+template <int EPI, int FM, int FN, bool PRE16 = false>
 __device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[FM][FN], int M, int N, int mb, int nb,
                                              int lane, float* wbuf, bool vec) {
     const int li = lane & 31, lh = lane >> 5;
@@ -58,6 +74,7 @@ __device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[FM
                 f32x4 bias_v = {0.f, 0.f, 0.f, 0.f};
                 if (e.bias && n < N) bias_v = *reinterpret_cast<const f32x4*>(e.bias + n);
                 f32x4 v[4], aux[4];
+                u32x2 aux16[4];
                 float rs[4];
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
@@ -68,7 +85,12 @@ __device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[FM
                     if (EPI == EPI_RES || EPI == EPI_GELUBWD) {
                         const float* ap = EPI == EPI_RES ? e.residual : e.gelu_pre;
                         const long ld = EPI == EPI_RES ? e.ldres : e.ldpre;
-                        aux[p] = ok ? *reinterpret_cast<const f32x4*>(ap + (long)m * ld + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        aux[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        aux16[p] = u32x2{0u, 0u};
+                        if (ok) {
+                            if constexpr (PRE16) aux16[p] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(ap) + (long)m * ld + n);
+                            else aux[p] = *reinterpret_cast<const f32x4*>(ap + (long)m * ld + n);
+                        }
                     }
                 }
 #pragma unroll
@@ -77,20 +99,21 @@ __device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[FM
                     if (m >= M || n >= N) continue;
                     f32x4 o = v[p] + bias_v;
                     if (EPI == EPI_GELUBWD) {
+                        const f32x4 pre = PRE16 ? widen_bf16x4(aux16[p]) : aux[p];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) o[c] *= gelu_grad_f(aux[p][c]);
+                        for (int c = 0; c < 4; ++c) o[c] *= gelu_grad_f(pre[c]);
                     }
                     if (has_rs) o *= rs[p];
                     if (EPI == EPI_RES) o += aux[p];
                     if (EPI == EPI_SPLIT2 && n >= e.col_split)
                         *reinterpret_cast<f32x4*>(e.C2 + (long)m * e.ldc2 + (n - e.col_split)) = o;
                     else
-                        *reinterpret_cast<f32x4*>(e.C + out_row(m) * e.ldc + n) = o;
+                        epi_store4(e.C, out_row(m) * e.ldc + n, o, e.c_bf16);
                     if (EPI == EPI_ACT) {
                         f32x4 a;
 #pragma unroll
                         for (int c = 0; c < 4; ++c) a[c] = gelu_f(o[c]);
-                        *reinterpret_cast<f32x4*>(e.Cact + (long)m * e.ldact + n) = a;
+                        epi_store4(e.Cact, (long)m * e.ldact + n, a, e.c_bf16);
                     }
                 }
             } else {

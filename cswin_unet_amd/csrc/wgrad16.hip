@@ -32,6 +32,7 @@ struct W16Problem {
     const float* dy; const float* x; const float* row_scale;
     float* slab;                    // [splits][N*K + N]
     int M, N, K, rows_per_sample, rows_per_split, tiles_n, tiles_k, has_bias;
+    int dy_bf16, x_bf16;            // the operand is stored as bf16 (bf16 activation storage)
     long slab_stride;
 };
 struct W16Batch {
@@ -43,12 +44,12 @@ struct W16Batch {
 // byte offset of 16-B chunk `ch` (8 bf16) of row `row` inside a [rows][128] bf16 image
 __device__ __forceinline__ int img_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
-__global__ __launch_bounds__(256) void wgrad16_kernel(W16Batch b) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * W16_MS * 256 + 8 * W16_T * 4];   // 2 stages x (dy | x) images + bias sums
-    int pi = 0;
-    while (pi + 1 < b.n && (int)blockIdx.x >= b.first[pi + 1]) ++pi;
-    const W16Problem& P = b.p[pi];
-    const int lb = (int)blockIdx.x - b.first[pi];
+constexpr int W16_LDS = 2 * 2 * W16_MS * 256 + 8 * W16_T * 4;      // 2 stages x (dy | x) images + bias sums
+
+// One problem's tile.  DY16 / X16: that operand is STORED as bf16 -- compile-time copies of the body (chosen per workgroup in
+// the kernel below): a run-time choice between 8-B and 16-B loads inside fetch() makes the prefetch loads wait for one another.
+template <bool DY16, bool X16>
+__device__ __forceinline__ void wgrad16_tile(const W16Problem& P, const int lb, unsigned char* lds) {
     const int tiles = P.tiles_n * P.tiles_k;
     const int split = lb / tiles, tile = lb - split * tiles;
     const int nb = (tile / P.tiles_k) * W16_T, kb = (tile % P.tiles_k) * W16_T;
@@ -65,14 +66,33 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(W16Batch b) {
     const float* dyp = P.dy + nb + 4 * lc;
     const float* xp = P.x + kb + 4 * lc;
     f32x4 gdy[4], gx[4];
+    u32x2 gdyh[4], gxh[4];          // raw chunks of a bf16-stored operand (INTEGER vectors: see widen_bf16x4 in gemm_epilogue.h)
     float grs[4];
     auto fetch = [&](int m0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = m0 + lr + 8 * j;
             const bool ok = m < m_end;
-            gdy[j] = (ok && n_ok) ? *reinterpret_cast<const f32x4*>(dyp + (long)m * P.N) : f32x4{0.f, 0.f, 0.f, 0.f};
-            gx[j] = (ok && k_ok) ? *reinterpret_cast<const f32x4*>(xp + (long)m * P.K) : f32x4{0.f, 0.f, 0.f, 0.f};
+            gdy[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gdyh[j] = u32x2{0u, 0u};
+            gxh[j] = u32x2{0u, 0u};
+            // bf16-stored operands arrive as raw bits in the two low lanes and are widened (dy) or passed through (x) in stash():
+            // a conversion here would make every prefetch wait for its own data
+            if (ok && n_ok) {
+                if constexpr (DY16) {
+                    gdyh[j] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(P.dy) + (long)m * P.N + nb + 4 * lc);
+                } else {
+                    gdy[j] = *reinterpret_cast<const f32x4*>(dyp + (long)m * P.N);
+                }
+            }
+            if (ok && k_ok) {
+                if constexpr (X16) {
+                    gxh[j] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(P.x) + (long)m * P.K + kb + 4 * lc);
+                } else {
+                    gx[j] = *reinterpret_cast<const f32x4*>(xp + (long)m * P.K);
+                }
+            }
             grs[j] = (P.row_scale && ok) ? P.row_scale[m / P.rows_per_sample] : 1.0f;
         }
     };
@@ -83,11 +103,16 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(W16Batch b) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = lr + 8 * j;
-            const f32x4 d = gdy[j] * grs[j];
+            f32x4 d = gdy[j];
+            if constexpr (DY16)
+                d = f32x4{__builtin_bit_cast(float, gdyh[j][0] << 16), __builtin_bit_cast(float, gdyh[j][0] & 0xffff0000u),
+                          __builtin_bit_cast(float, gdyh[j][1] << 16), __builtin_bit_cast(float, gdyh[j][1] & 0xffff0000u)};
+            d *= grs[j];
             bsum += d;
             const int off = img_off(r, lc >> 1) + 8 * (lc & 1);
             *reinterpret_cast<bf16x4v*>(dimg + off) = __builtin_convertvector(d, bf16x4v);
-            *reinterpret_cast<bf16x4v*>(ximg + off) = __builtin_convertvector(gx[j], bf16x4v);
+            if constexpr (X16) *reinterpret_cast<u32x2*>(ximg + off) = gxh[j];
+            else *reinterpret_cast<bf16x4v*>(ximg + off) = __builtin_convertvector(gx[j], bf16x4v);
         }
     };
 
@@ -170,6 +195,21 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(W16Batch b) {
     }
 }
 
+__global__ __launch_bounds__(256) void wgrad16_kernel(W16Batch b) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[W16_LDS];
+    int pi = 0;
+    while (pi + 1 < b.n && (int)blockIdx.x >= b.first[pi + 1]) ++pi;
+    const W16Problem& P = b.p[pi];
+    const int lb = (int)blockIdx.x - b.first[pi];
+    if (P.dy_bf16) {
+        if (P.x_bf16) wgrad16_tile<true, true>(P, lb, lds);
+        else wgrad16_tile<true, false>(P, lb, lds);
+    } else {
+        if (P.x_bf16) wgrad16_tile<false, true>(P, lb, lds);
+        else wgrad16_tile<false, false>(P, lb, lds);
+    }
+}
+
 }  // namespace
 
 // Internal entry used by gemm.hip's cswin_linear_bwd_weight_batch in bf16 matmul mode.  Problems must be 16-B aligned with
@@ -186,6 +226,8 @@ int cswin_wgrad16_batch(const cswin_wgrad_desc* d, int n, const int* splits, con
         P.rows_per_split = rows_per_split[i];
         P.tiles_n = cdiv(P.N, W16_T); P.tiles_k = cdiv(P.K, W16_T);
         P.has_bias = d[i].dbias != nullptr;
+        P.dy_bf16 = d[i].io_bf16 & 1;
+        P.x_bf16 = (d[i].io_bf16 >> 1) & 1;
         P.slab_stride = (long)P.N * P.K + P.N;
         b.first[i] = blocks;
         blocks += P.tiles_n * P.tiles_k * splits[i];

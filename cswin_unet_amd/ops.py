@@ -10,7 +10,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from ._lib import ReduceJob, WgradDesc, call, dev_f32, lib, precision, ptr, stream
+from ._lib import ReduceJob, WgradDesc, act_bf16, call, dev_f32, lib, precision, ptr, stream
 
 __all__ = ["layer_norm", "linear", "linear_pair", "mlp", "stripe_attention", "cswin_block", "conv_tokens", "patch_embed_conv", "carafe_reassemble",
            "tokens_to_nchw", "matmul_nn", "ce_dice_loss", "dropout", "img2windows", "windows2img"]
@@ -141,7 +141,7 @@ class _Linear(Function):
         y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
         rps = _rows_per_sample(x) if row_scale is not None else 1
         call("cswin_linear_fwd", ptr(x), ptr(x2), K1 if x2 is not None else 0, ptr(w), ptr(b), ptr(y), None, ptr(residual),
-             ptr(row_scale), rps, M, N, K, precision(), stream())
+             ptr(row_scale), rps, M, N, K, precision(), 0, stream())
         ctx.save_for_backward(x, w, x2, row_scale)
         ctx.has_bias, ctx.has_res, ctx.rps = b is not None, residual is not None, rps
         return y
@@ -160,7 +160,7 @@ class _Linear(Function):
             dx = torch.empty_like(x)
             dx2 = torch.empty_like(x2) if x2 is not None else None
             call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), ptr(dx2), K1 if x2 is not None else 0, None,
-                 ptr(row_scale), ctx.rps, None, M, N, K, precision(), stream())
+                 ptr(row_scale), ctx.rps, None, M, N, K, precision(), 0, stream())
         if need[1]:
             with _side_stream(dy, x, x2, row_scale):
                 dw = torch.empty_like(w)
@@ -192,7 +192,7 @@ class _LinearPair(Function):
         for w, b in ((w1, b1), (w2, b2)):
             assert w.shape[1] == K
             y = torch.empty(x.shape[:-1] + (w.shape[0],), dtype=torch.float32, device=x.device)
-            call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, w.shape[0], K, precision(), stream())
+            call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, w.shape[0], K, precision(), 0, stream())
             ys.append(y)
         ctx.save_for_backward(x, w1, w2)
         ctx.has_b = (b1 is not None, b2 is not None)
@@ -209,8 +209,8 @@ class _LinearPair(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            call("cswin_linear_bwd_data", ptr(dy1), ptr(w1), ptr(dx), None, 0, None, None, 1, None, M, w1.shape[0], K, precision(), st)
-            call("cswin_linear_bwd_data", ptr(dy2), ptr(w2), ptr(dx), None, 0, None, None, 1, ptr(dx), M, w2.shape[0], K, precision(), st)
+            call("cswin_linear_bwd_data", ptr(dy1), ptr(w1), ptr(dx), None, 0, None, None, 1, None, M, w1.shape[0], K, precision(), 0, st)
+            call("cswin_linear_bwd_data", ptr(dy2), ptr(w2), ptr(dx), None, 0, None, None, 1, ptr(dx), M, w2.shape[0], K, precision(), 0, st)
         grads, keep = [], []
         wg, jobs = (WgradDesc * 2)(), (ReduceJob * 2)()
         for i, (dy, w, has_b) in enumerate(((dy1, w1, ctx.has_b[0]), (dy2, w2, ctx.has_b[1]))):
@@ -248,17 +248,17 @@ class _Mlp(Function):
         M = x.numel() // K
         pre = torch.empty(x.shape[:-1] + (Hd,), dtype=torch.float32, device=x.device)
         act = torch.empty_like(pre)
-        call("cswin_linear_fwd", ptr(x), None, 0, ptr(w1), ptr(b1), ptr(pre), ptr(act), None, None, 1, M, Hd, K, precision(), stream())
+        call("cswin_linear_fwd", ptr(x), None, 0, ptr(w1), ptr(b1), ptr(pre), ptr(act), None, None, 1, M, Hd, K, precision(), 0, stream())
         y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
         rps = _rows_per_sample(x) if row_scale is not None else 1
         if drop_p > 0:
             call("cswin_dropout", ptr(act), None, None, ptr(act), act.numel(), act.numel() // act.shape[0], drop_p, seeds[0], stream())
-            call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(b2), ptr(y), None, None, None, 1, M, N, Hd, precision(), stream())
+            call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(b2), ptr(y), None, None, None, 1, M, N, Hd, precision(), 0, stream())
             call("cswin_dropout", ptr(y), ptr(residual), ptr(row_scale), ptr(y), y.numel(), y.numel() // y.shape[0], drop_p, seeds[1],
                  stream())
         else:
             call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(b2), ptr(y), None, ptr(residual), ptr(row_scale), rps,
-                 M, N, Hd, precision(), stream())
+                 M, N, Hd, precision(), 0, stream())
         ctx.save_for_backward(x, w1, w2, pre, act, row_scale)
         ctx.has_res, ctx.rps, ctx.has_b1, ctx.has_b2 = residual is not None, rps, b1 is not None, b2 is not None
         ctx.drop = (float(drop_p), seeds)
@@ -283,13 +283,13 @@ class _Mlp(Function):
         # d pre = (row_scale * dy @ w2) * gelu'(pre)   (GELU backward fused into the data-gradient epilogue)
         dpre = torch.empty_like(pre)
         call("cswin_linear_bwd_data", ptr(dyl), ptr(w2), ptr(dpre), None, 0, ptr(pre), ptr(rs_gemm), ctx.rps, None, M, N,
-             Hd, precision(), st)
+             Hd, precision(), 0, st)
         if drop_p > 0:
             call("cswin_dropout", ptr(dpre), None, None, ptr(dpre), dpre.numel(), dpre.numel() // dpre.shape[0], drop_p, seeds[0], st)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            call("cswin_linear_bwd_data", ptr(dpre), ptr(w1), ptr(dx), None, 0, None, None, 1, None, M, Hd, K, precision(), st)
+            call("cswin_linear_bwd_data", ptr(dpre), ptr(w1), ptr(dx), None, 0, None, None, 1, None, M, Hd, K, precision(), 0, st)
         with _side_stream(dyl, act, dpre, x, rs_gemm):          # both weight gradients, off the data-gradient chain
             dw2 = torch.empty_like(w2)
             db2 = torch.empty(N, dtype=torch.float32, device=dev) if ctx.has_b2 else None
@@ -320,7 +320,7 @@ class _MatmulNN(Function):
         M, N = a.shape
         K = b.shape[1]
         c = torch.empty(M, K, dtype=torch.float32, device=a.device)
-        call("cswin_linear_bwd_data", ptr(a), ptr(b), ptr(c), None, 0, None, None, 1, None, M, N, K, precision(), stream())
+        call("cswin_linear_bwd_data", ptr(a), ptr(b), ptr(c), None, 0, None, None, 1, None, M, N, K, precision(), 0, stream())
         ctx.save_for_backward(a, b)
         return c
 
@@ -332,7 +332,7 @@ class _MatmulNN(Function):
         M, N = a.shape
         K = b.shape[1]
         da = torch.empty_like(a)        # da = dc @ b^T
-        call("cswin_linear_fwd", ptr(dc), None, 0, ptr(b), None, ptr(da), None, None, None, 1, M, N, K, precision(), stream())
+        call("cswin_linear_fwd", ptr(dc), None, 0, ptr(b), None, ptr(da), None, None, None, 1, M, N, K, precision(), 0, stream())
         db = torch.empty_like(b)        # db (N, K) = a^T @ dc
         nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
         ws = _ws(nbytes, a.device)
@@ -350,7 +350,9 @@ def matmul_nn(a, b):
 class _StripeAttention(Function):
     @staticmethod
     def forward(ctx, qkv, reso, split, idx, heads, scale, *wb):
-        qkv = dev_f32(qkv, "attention qkv")
+        # qkv may arrive STORED as bf16 (the bf16 mode's activation storage): the kernel widens on load, dqkv comes back as bf16
+        q16 = qkv.dtype == torch.bfloat16 and qkv.is_cuda
+        qkv = qkv.contiguous() if q16 else dev_f32(qkv, "attention qkv")
         nb = len(idx)
         ws_ = [dev_f32(t).view(t.shape[0], 9) for t in wb[:nb]]
         bs_ = [dev_f32(t) for t in wb[nb:]]
@@ -361,7 +363,7 @@ class _StripeAttention(Function):
         y = torch.empty(B, L, C, dtype=torch.float32, device=qkv.device)
         lse = torch.empty(B, sum(heads), L, dtype=torch.float32, device=qkv.device)
         call("cswin_attn_fwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(y), ptr(lse), B, reso, C, nb,
-             _int_array(heads), _int_array(idx), split, float(scale or 0.0), stream())
+             _int_array(heads), _int_array(idx), split, float(scale or 0.0), int(q16), stream())
         ctx.save_for_backward(qkv, lse, y, *ws_, *bs_)
         ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0))
         return y
@@ -383,7 +385,7 @@ class _StripeAttention(Function):
         nbytes = lib().cswin_attn_bwd_workspace(B, reso, C, nb, ha, ia, split)
         ws = _ws(nbytes, qkv.device)
         call("cswin_attn_bwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(lse), ptr(y), ptr(dy), ptr(dqkv), _ptr_array(dws),
-             _ptr_array(dbs), ptr(ws), nbytes, B, reso, C, nb, ha, ia, split, scale, None, stream())
+             _ptr_array(dbs), ptr(ws), nbytes, B, reso, C, nb, ha, ia, split, scale, None, int(qkv.dtype == torch.bfloat16), stream())
         return (dqkv, None, None, None, None, None) + tuple(d.view(d.shape[0], 1, 3, 3) for d in dws) + tuple(dbs)
 
 
@@ -416,32 +418,36 @@ class _CSWinBlock(Function):
         lb = [dev_f32(t) for t in lepe[nb:]]
         rs1, rs2 = dev_f32(rs1), dev_f32(rs2)
         E = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        # bf16 mode: the tensors that only GEMMs and the attention kernel read -- qkv, the MLP hidden pair and (backward) their
+        # gradients -- are STORED as bf16 (the largest tensors of a block: 3C and 2 x 4C wide); everything else stays fp32
+        s16 = act_bf16() and C % 4 == 0
+        E16 = (lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=dev)) if s16 else E
         h1, m1, r1 = torch.empty_like(x), E(M), E(M)
         call("cswin_layernorm_fwd", ptr(x), ptr(g1), ptr(b1), ptr(h1), ptr(m1), ptr(r1), M, C, eps1, st)
-        qkv = E(B, L, 3 * C)
-        call("cswin_linear_fwd", ptr(h1), None, 0, ptr(wqkv), ptr(bqkv), ptr(qkv), None, None, None, 1, M, 3 * C, C, precision(), st)
+        qkv = E16(B, L, 3 * C)
+        call("cswin_linear_fwd", ptr(h1), None, 0, ptr(wqkv), ptr(bqkv), ptr(qkv), None, None, None, 1, M, 3 * C, C, precision(), 2 if s16 else 0, st)
         att, lse = E(B, L, C), E(B, sum(heads), L)
         ha, ia = _int_array(heads), _int_array(idx)
         call("cswin_attn_fwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(att), ptr(lse), B, reso, C, nb, ha, ia, split,
-             float(scale or 0.0), st)
+             float(scale or 0.0), int(s16), st)
         x1 = torch.empty_like(x)
-        call("cswin_linear_fwd", ptr(att), None, 0, ptr(wp), ptr(bp), ptr(x1), None, ptr(x), ptr(rs1), L, M, C, C, precision(), st)
+        call("cswin_linear_fwd", ptr(att), None, 0, ptr(wp), ptr(bp), ptr(x1), None, ptr(x), ptr(rs1), L, M, C, C, precision(), 0, st)
         h2, m2, r2 = torch.empty_like(x), E(M), E(M)
         call("cswin_layernorm_fwd", ptr(x1), ptr(g2), ptr(b2), ptr(h2), ptr(m2), ptr(r2), M, C, eps2, st)
         Hd = w1.shape[0]
-        pre, act = E(B, L, Hd), E(B, L, Hd)
-        call("cswin_linear_fwd", ptr(h2), None, 0, ptr(w1), ptr(bb1), ptr(pre), ptr(act), None, None, 1, M, Hd, C, precision(), st)
+        pre, act = E16(B, L, Hd), E16(B, L, Hd)
+        call("cswin_linear_fwd", ptr(h2), None, 0, ptr(w1), ptr(bb1), ptr(pre), ptr(act), None, None, 1, M, Hd, C, precision(), 2 if s16 else 0, st)
         y = torch.empty_like(x)
-        call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(bb2), ptr(y), None, ptr(x1), ptr(rs2), L, M, C, Hd, precision(), st)
+        call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(bb2), ptr(y), None, ptr(x1), ptr(rs2), L, M, C, Hd, precision(), 1 if s16 else 0, st)
         ctx.save_for_backward(x, m1, r1, h1, qkv, lse, att, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lw, *lb)
-        ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0), bqkv is not None)
+        ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0), bqkv is not None, s16)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
         (x, m1, r1, h1, qkv, lse, att, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lwb) = ctx.saved_tensors
-        reso, split, idx, heads, scale, has_qkv_bias = ctx.meta
+        reso, split, idx, heads, scale, has_qkv_bias, s16 = ctx.meta
         lw, lb = lwb[:len(idx)], lwb[len(idx):]
         dy = dev_f32(dy)
         B, L, C = x.shape
@@ -460,28 +466,29 @@ class _CSWinBlock(Function):
         J = lambda i: ctypes.cast(ctypes.byref(jobs[i]), ctypes.c_void_p)
         # ---- MLP branch ----
         dpre = torch.empty_like(pre)
-        call("cswin_linear_bwd_data", ptr(dy), ptr(w2), ptr(dpre), None, 0, ptr(pre), ptr(rs2), L, None, M, C, Hd, precision(), st)
+        call("cswin_linear_bwd_data", ptr(dy), ptr(w2), ptr(dpre), None, 0, ptr(pre), ptr(rs2), L, None, M, C, Hd, precision(), 10 if s16 else 0, st)
         # the four weight gradients are off the critical path: they run as ONE batched launch once all operands exist
         wg = (WgradDesc * 4)()
 
-        def defer_wgrad(slot, dy_, x_, rs_, dw_, db_, wsi, N_, K_):
+        def defer_wgrad(slot, dy_, x_, rs_, dw_, db_, wsi, N_, K_, io=0):
+            wg[slot].io_bf16 = io if s16 else 0
             wg[slot].dy, wg[slot].x, wg[slot].row_scale = dy_.data_ptr(), x_.data_ptr(), (rs_.data_ptr() if rs_ is not None else None)
             wg[slot].dw, wg[slot].dbias = dw_.data_ptr(), (db_.data_ptr() if db_ is not None else None)
             wg[slot].workspace, wg[slot].ws_bytes = wsp[wsi].value, sizes[wsi]
             wg[slot].rows_per_sample, wg[slot].M, wg[slot].N, wg[slot].K, wg[slot].precision = L, M, N_, K_, precision()
 
         dw2, db2 = torch.empty_like(w2), E(C)
-        defer_wgrad(0, dy, act, rs2, dw2, db2, 0, C, Hd)
+        defer_wgrad(0, dy, act, rs2, dw2, db2, 0, C, Hd, io=2)          # x = act is stored as bf16
         dw1, db1 = torch.empty_like(w1), E(Hd)
-        defer_wgrad(1, dpre, h2, None, dw1, db1, 1, Hd, C)
+        defer_wgrad(1, dpre, h2, None, dw1, db1, 1, Hd, C, io=1)        # dy = dpre is stored as bf16
         dh2 = torch.empty_like(x)
-        call("cswin_linear_bwd_data", ptr(dpre), ptr(w1), ptr(dh2), None, 0, None, None, 1, None, M, Hd, C, precision(), st)
+        call("cswin_linear_bwd_data", ptr(dpre), ptr(w1), ptr(dh2), None, 0, None, None, 1, None, M, Hd, C, precision(), 1 if s16 else 0, st)
         dx1, dg2, dbt2 = torch.empty_like(x), E(C), E(C)
         call("cswin_layernorm_bwd", ptr(dh2), ptr(x1), ptr(m2), ptr(r2), ptr(g2), ptr(dy), ptr(dx1), ptr(dg2), ptr(dbt2), wsp[2],
              sizes[2], M, C, J(2), st)
         # ---- attention branch ----
         datt = dh2                                                     # reuse
-        call("cswin_linear_bwd_data", ptr(dx1), ptr(wp), ptr(datt), None, 0, None, ptr(rs1), L, None, M, C, C, precision(), st)
+        call("cswin_linear_bwd_data", ptr(dx1), ptr(wp), ptr(datt), None, 0, None, ptr(rs1), L, None, M, C, C, precision(), 0, st)
         dwp, dbp = torch.empty_like(wp), E(C)
         defer_wgrad(2, dx1, att, rs1, dwp, dbp, 3, C, C)
         early = None
@@ -501,10 +508,10 @@ class _CSWinBlock(Function):
         naw = h.cswin_attn_bwd_workspace(B, reso, C, nb, ha, ia, split)
         aws = _ws(naw, dev)
         call("cswin_attn_bwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(lse), ptr(att), ptr(datt), ptr(dqkv),
-             _ptr_array(dlw), _ptr_array(dlb), ptr(aws), naw, B, reso, C, nb, ha, ia, split, scale, J(6), st)
+             _ptr_array(dlw), _ptr_array(dlb), ptr(aws), naw, B, reso, C, nb, ha, ia, split, scale, J(6), int(s16), st)
         dwqkv = torch.empty_like(wqkv)
         dbqkv = E(3 * C) if has_qkv_bias else None
-        defer_wgrad(3, dqkv, h1, None, dwqkv, dbqkv, 4, 3 * C, C)
+        defer_wgrad(3, dqkv, h1, None, dwqkv, dbqkv, 4, 3 * C, C, io=1)  # dy = dqkv is stored as bf16
         wjobs = (ReduceJob * 4)()
         if early is not None:
             call("cswin_linear_bwd_weight_batch", ctypes.cast(ctypes.byref(wg[3]), ctypes.c_void_p), 1,
@@ -516,7 +523,7 @@ class _CSWinBlock(Function):
         for slot, ji in enumerate((0, 1, 3, 4)):
             jobs[ji] = wjobs[slot]
         dh1 = datt                                                     # reuse again
-        call("cswin_linear_bwd_data", ptr(dqkv), ptr(wqkv), ptr(dh1), None, 0, None, None, 1, None, M, 3 * C, C, precision(), st)
+        call("cswin_linear_bwd_data", ptr(dqkv), ptr(wqkv), ptr(dh1), None, 0, None, None, 1, None, M, 3 * C, C, precision(), 1 if s16 else 0, st)
         dx, dg1, dbt1 = torch.empty_like(x), E(C), E(C)
         call("cswin_layernorm_bwd", ptr(dh1), ptr(x), ptr(m1), ptr(r1), ptr(g1), ptr(dx1), ptr(dx), ptr(dg1), ptr(dbt1), wsp[5],
              sizes[5], M, C, J(5), st)

@@ -62,7 +62,7 @@ int cswin_device_ok(void); /* 1 if the current HIP device is gfx950 */
  * lse (B, sum(heads), L): row log-sum-exp saved for backward.  scale <= 0 selects head_dim^-0.5 (:42). */
 int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, float* y, float* lse,
                    int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split, float scale,
-                   void* stream);
+                   int qkv_bf16, void* stream);
 size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split);
 /* autograd backward of the above: dqkv (B, L, 3C), dlepe_w[i] (Cb, 9), dlepe_b[i] (Cb) are overwritten.
  * y (the forward output) and lepe_b are only read for windows of more than 112 tokens (384x384 inputs), where a
@@ -71,7 +71,9 @@ size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* 
 int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, const float* lse,
                    const float* y, const float* dy, float* dqkv, float* const* dlepe_w, float* const* dlepe_b,
                    void* workspace, size_t ws_bytes, int B, int reso, int C, int nbranch, const int* heads, const int* idx,
-                   int split, float scale, cswin_reduce_job* deferred, void* stream);
+                   int split, float scale, cswin_reduce_job* deferred, int qkv_bf16, void* stream);
+/* qkv_bf16 != 0: qkv (and dqkv) are STORED as bf16 -- the output format of cswin_linear_fwd(io_bf16 bit 1) --; the arithmetic of
+ * the attention kernels stays fp32. */
 
 /* ---- img2windows / windows2img (cswin_unet.py:184-202): index-only, bit-exact ----
  * img (B, C, H, W) -> out (B*nH*nW, H_sp*W_sp, C);   win (B*nH*nW, H_sp*W_sp, C) -> out (B, H, W, C) */
@@ -96,11 +98,13 @@ int cswin_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
  * x2 == NULL: single source.  row_scale may be NULL (= 1). */
 int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* w, const float* bias, float* y,
                      float* y_act, const float* residual, const float* row_scale, int rows_per_sample, int M, int N,
-                     int K, int precision, void* stream);
-/* dx (M, K) = add + row_scale * ((dy (M, N) @ w (N, K)) * gelu'(gelu_pre));  columns >= k_split go to dx2 if given */
+                     int K, int precision, int io_bf16, void* stream);
+/* io_bf16 (precision 1 only; 0 = every tensor fp32): activations STORED as bf16 in HBM, fp32 accumulation as before.
+ *   cswin_linear_fwd:      bit 0 = x, bit 1 = y and y_act;     cswin_linear_bwd_data: bit 0 = dy, bit 1 = dx, bit 3 = gelu_pre.
+ * dx (M, K) = add + row_scale * ((dy (M, N) @ w (N, K)) * gelu'(gelu_pre));  columns >= k_split go to dx2 if given */
 int cswin_linear_bwd_data(const float* dy, const float* w, float* dx, float* dx2, int k_split, const float* gelu_pre,
                           const float* row_scale, int rows_per_sample, const float* add, int M, int N, int K,
-                          int precision, void* stream);
+                          int precision, int io_bf16, void* stream);
 size_t cswin_linear_bwd_weight_workspace(int M, int N, int K);
 /* dw (N, K) = (row_scale * dy)^T @ [x | x2];  dbias (N) = column sums (may be NULL); `deferred` as for layernorm_bwd */
 int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, int k_split, const float* row_scale,
@@ -117,6 +121,7 @@ typedef struct cswin_wgrad_desc {
     size_t ws_bytes;
     int rows_per_sample, M, N, K;
     int precision;           /* 0 = exact fp32 MFMA, 1 = bf16 operands (all problems of one launch agree) */
+    int io_bf16;             /* precision 1 only: bit 0 = dy is stored as bf16, bit 1 = x is stored as bf16 */
 } cswin_wgrad_desc;
 /* Up to 4 independent weight gradients (the four nn.Linear of a CSWinBlock, cswin_unet.py:125,134,17-19) in ONE launch;
  * deferred[0..n) receive their slab reductions (required: run them with cswin_rows_sum_multi). */

@@ -784,6 +784,141 @@ def _bf16_step_vs_oracle(N, ops, cfg, net, img, lab, tag, grads):
         assert e < BF16_GRAD_L2, (n, e)
 
 
+@pytest.mark.parametrize("M,Nn,K", [(4704, 768, 256), (1176, 512, 2048), (3000, 64, 64)])
+def test_linear_bf16_storage_flags_bit_exact(M, Nn, K):
+    """io_bf16 of cswin_linear_fwd / cswin_linear_bwd_data / cswin_wgrad_desc (include/cswin_hip.h): a tensor STORED as bf16 must
+    give bit-identical results to the same values held in fp32 (the operands are rounded to bf16 either way, and a bf16 -> fp32
+    -> bf16 round trip is exact), and an OUTPUT stored as bf16 must equal the fp32 output rounded to nearest even."""
+    import ctypes
+    from cswin_unet_amd._lib import ReduceJob, WgradDesc, call, lib, ptr, stream
+    x16 = T(det_normal("st16.x", (M, K))).bfloat16()
+    dy16 = T(det_normal("st16.dy", (M, Nn))).bfloat16()
+    w, b = T(det_normal("st16.w", (Nn, K)) * 0.05), T(det_normal("st16.b", (Nn,)))
+    x32, dy32 = x16.float(), dy16.float()
+    E = lambda *sh, dt=torch.float32: torch.empty(*sh, dtype=dt, device=DEV)
+    eq = lambda a, c: bool((a.view(torch.int16) == c.view(torch.int16)).all()) if a.dtype == torch.bfloat16 else bool((a == c).all())
+    # forward, plain and GELU pair: x stored bf16 (1), outputs stored bf16 (2), both (3)
+    y32, p32, a32 = E(M, Nn), E(M, Nn), E(M, Nn)
+    call("cswin_linear_fwd", ptr(x32), None, 0, ptr(w), ptr(b), ptr(y32), None, None, None, 1, M, Nn, K, 1, 0, stream())
+    call("cswin_linear_fwd", ptr(x32), None, 0, ptr(w), ptr(b), ptr(p32), ptr(a32), None, None, 1, M, Nn, K, 1, 0, stream())
+    for io in (1, 2, 3):
+        dt = torch.bfloat16 if io & 2 else torch.float32
+        y, pre, act = E(M, Nn, dt=dt), E(M, Nn, dt=dt), E(M, Nn, dt=dt)
+        xin = x16 if io & 1 else x32
+        call("cswin_linear_fwd", ptr(xin), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, Nn, K, 1, io, stream())
+        call("cswin_linear_fwd", ptr(xin), None, 0, ptr(w), ptr(b), ptr(pre), ptr(act), None, None, 1, M, Nn, K, 1, io, stream())
+        assert eq(y, y32.to(dt)) and eq(pre, p32.to(dt)) and eq(act, a32.to(dt)), ("fwd", io)
+    # forward with residual + row scale: x stored bf16, output fp32
+    res, rs = T(det_normal("st16.res", (M, Nn))), T(np.array([0.5, 0.0, 1.5], np.float32))
+    rps = (M + 2) // 3
+    r32, r16 = E(M, Nn), E(M, Nn)
+    call("cswin_linear_fwd", ptr(x32), None, 0, ptr(w), ptr(b), ptr(r32), None, ptr(res), ptr(rs), rps, M, Nn, K, 1, 0, stream())
+    call("cswin_linear_fwd", ptr(x16), None, 0, ptr(w), ptr(b), ptr(r16), None, ptr(res), ptr(rs), rps, M, Nn, K, 1, 1, stream())
+    assert eq(r16, r32), "fwd residual"
+    # data gradient: dy stored bf16 (1), dx stored bf16 (2), GELU' argument stored bf16 (8), with and without the row scale
+    pre16 = T(det_normal("st16.pre", (M, K))).bfloat16()
+    pre32f = pre16.float()
+    for io, use_pre, use_rs in [(1, False, False), (2, False, False), (3, False, True), (8, True, False), (10, True, True), (11, True, True)]:
+        dx32 = E(M, K)
+        call("cswin_linear_bwd_data", ptr(dy32), ptr(w), ptr(dx32), None, 0, ptr(pre32f) if use_pre else None,
+             ptr(rs) if use_rs else None, rps if use_rs else 1, None, M, Nn, K, 1, 0, stream())
+        dx = E(M, K, dt=torch.bfloat16 if io & 2 else torch.float32)
+        call("cswin_linear_bwd_data", ptr(dy16 if io & 1 else dy32), ptr(w), ptr(dx), None, 0,
+             ptr(pre16 if io & 8 else pre32f) if use_pre else None, ptr(rs) if use_rs else None, rps if use_rs else 1, None,
+             M, Nn, K, 1, io, stream())
+        assert eq(dx, dx32.to(dx.dtype)), ("bwd_data", io)
+    # weight gradient batch: dy stored bf16 (1), x stored bf16 (2)
+    nbytes = lib().cswin_linear_bwd_weight_workspace(M, Nn, K)
+
+    def wgrad(io, with_rs):
+        wg, jobs = (WgradDesc * 1)(), (ReduceJob * 1)()
+        dw, db, ws = E(Nn, K), E(Nn), E(nbytes // 4 + 4)
+        dyt, xt = (dy16 if io & 1 else dy32), (x16 if io & 2 else x32)
+        wg[0].dy, wg[0].x, wg[0].row_scale = dyt.data_ptr(), xt.data_ptr(), (rs.data_ptr() if with_rs else None)
+        wg[0].dw, wg[0].dbias, wg[0].workspace, wg[0].ws_bytes = dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nbytes
+        wg[0].rows_per_sample, wg[0].M, wg[0].N, wg[0].K, wg[0].precision, wg[0].io_bf16 = rps, M, Nn, K, 1, io
+        call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 1, ctypes.cast(jobs, ctypes.c_void_p), stream())
+        call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), 1, stream())
+        torch.cuda.synchronize()
+        return dw, db
+
+    for with_rs in (False, True):
+        dw0, db0 = wgrad(0, with_rs)
+        for io in (1, 2, 3):
+            dw, db = wgrad(io, with_rs)
+            assert eq(dw, dw0) and eq(db, db0), ("wgrad", io, with_rs)
+    # flags outside the contract are refused, not ignored
+    from cswin_unet_amd._lib import CswinHipError
+    with pytest.raises(CswinHipError):
+        call("cswin_linear_fwd", ptr(x16), None, 0, ptr(w), ptr(b), ptr(y32), None, None, None, 1, M, Nn, K, 0, 1, stream())
+    with pytest.raises(CswinHipError):
+        call("cswin_linear_fwd", ptr(x16), None, 0, ptr(w), ptr(b), ptr(r32), None, ptr(res), None, 1, M, Nn, K, 1, 2, stream())
+
+
+@pytest.mark.parametrize("reso,idx,split,dim,heads", [(56, 0, 1, 64, 2), (28, 1, 2, 128, 4), (14, 0, 7, 256, 8), (7, -1, 7, 512, 16),
+                                                      (24, 1, 12, 64, 2)])
+def test_attention_bf16_qkv_storage_bit_exact(ops, reso, idx, split, dim, heads):
+    """qkv_bf16 of cswin_attn_fwd / cswin_attn_bwd: q, k, v STORED as bf16 give bit-identical y / LePE gradients to the same
+    values held in fp32 (all arithmetic is fp32 either way) and dqkv equals the fp32 dqkv rounded to nearest even.  Covers the
+    thin-stripe, 7 x 7, whole-map (last stage) and large-window (two-pass backward) kernels."""
+    B = 2
+    C = dim if idx == -1 else dim // 2
+    nh = heads if idx == -1 else heads // 2
+    qkv16 = T(det_normal(f"att16.{reso}.{idx}.qkv", (B, reso * reso, 3 * C))).bfloat16()
+    lw = T(det_normal(f"att16.{reso}.lw", (C, 1, 3, 3)) * 0.3)
+    lb = T(det_normal(f"att16.{reso}.lb", (C,)) * 0.1)
+    dy = T(det_normal(f"att16.{reso}.{idx}.dy", (B, reso * reso, C)))
+    outs = []
+    for q in (qkv16, qkv16.float()):
+        q = q.clone().requires_grad_()
+        w_, b_ = lw.clone().requires_grad_(), lb.clone().requires_grad_()
+        y = ops.stripe_attention(q, reso, split, [idx], [nh], [w_], [b_])
+        y.backward(dy)
+        outs.append((y.detach(), q.grad, w_.grad, b_.grad))
+    (y16, dq16, dw16, db16), (y32, dq32, dw32, db32) = outs
+    assert dq16.dtype == torch.bfloat16 and y16.dtype == torch.float32
+    assert bool((y16 == y32).all()), "attention output differs"
+    assert bool((dw16 == dw32).all()) and bool((db16 == db32).all()), "LePE gradients differ"
+    assert bool((dq16.view(torch.int16) == dq32.bfloat16().view(torch.int16)).all()), "dqkv is not the rounded fp32 dqkv"
+
+
+@pytest.mark.parametrize("dim,reso,heads,split,last", [(64, 56, 2, 1, False), (256, 14, 8, 7, False), (512, 7, 16, 7, True)])
+def test_block_bf16_activation_storage(N, bf16_matmul, dim, reso, heads, split, last):
+    """bf16 mode stores qkv, the MLP hidden pair and their gradients as bf16 (ops._CSWinBlock; include/cswin_hip.h io_bf16 /
+    qkv_bf16).  As GEMM operands those tensors were rounded to bf16 anyway; what storage adds is one rounding (relative 2^-9
+    uniform: sigma 1.1e-3 per element) of q, k, v before the attention kernel and of the GELU argument before GELU'.  So against the
+    same block with fp32 storage (same bf16 operands) every output must agree to a few sigma in L2 -- bound 1e-2 -- and must NOT be
+    identical (the storage path is live); against the fp32 oracle the whole-model bounds above apply."""
+    import cswin_unet_amd
+    blk = N.CSWinBlock(dim=dim, reso=reso, num_heads=heads, split_size=split, mlp_ratio=4., qkv_bias=True, drop_path=0.,
+                       last_stage=last).to(DEV)
+    fill_state_dict(blk)
+    x = det_normal(f"store16.{dim}.x", (2, reso * reso, dim))
+    dy = T(det_normal(f"store16.{dim}.dy", (2, reso * reso, dim)))
+
+    def run(storage):
+        prev = cswin_unet_amd.set_activation_storage(storage)
+        try:
+            blk.zero_grad(set_to_none=True)
+            xi = T(x, True)
+            y = blk(xi)
+            y.backward(dy)
+            return [y.detach().clone(), xi.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
+        finally:
+            cswin_unet_amd.set_activation_storage(prev)
+
+    a, b = run("bf16"), run("fp32")
+    names = ["y", "dx"] + [n for n, _ in blk.named_parameters()]
+    differ = False
+    for n, u, v in zip(names, a, b):
+        e = _rel_l2(u, v)
+        with open(LOG, "a") as f:
+            f.write(f"store16.c{dim}.{n} l2 {e:.3e}\n")
+        assert e < 1e-2, (n, e)
+        differ |= e > 1e-6
+    assert differ, "bf16 storage produced bit-identical results: the storage path did not run"
+
+
 def test_model_bf16_384_step_vs_oracle(N, ops, bf16_matmul):
     """BASELINE configs[3] in its own precision: 384 x 384 (split [1,2,12,12]: large-window attention paths), bf16 operands, B = 1,
     against the fp32 oracle with the derived bounds."""

@@ -35,8 +35,8 @@ for name, M, N, K in shapes:
     dw = torch.empty(N, K, device="cuda"); db = torch.empty(N, device="cuda")
     nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
     ws = torch.empty(nbytes // 4 + 4, device="cuda")
-    tf = timed(lambda: call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, precision(), stream()))
-    tdx = timed(lambda: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, precision(), stream()))
+    tf = timed(lambda: call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, precision(), 0, stream()))
+    tdx = timed(lambda: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, precision(), 0, stream()))
     tdw = timed(lambda: call("cswin_linear_bwd_weight", ptr(dy), ptr(x), None, 0, None, 1, ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, None, precision(), stream()))
     fl = 2.0 * M * N * K
     c = counts[name[:2]]

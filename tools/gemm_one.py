@@ -12,7 +12,7 @@ dw = torch.empty(N, K, device="cuda"); db = torch.empty(N, device="cuda")
 nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
 ws = torch.empty(nbytes // 4 + 4, device="cuda")
 for _ in range(reps):
-    call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, precision(), stream())
-    call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, precision(), stream())
+    call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, precision(), 0, stream())
+    call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, precision(), 0, stream())
     call("cswin_linear_bwd_weight", ptr(dy), ptr(x), None, 0, None, 1, ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, None, precision(), stream())
 torch.cuda.synchronize()

@@ -29,7 +29,7 @@ for name, M, N, K in [("s3.qkv", 4704, 768, 256), ("s3.proj", 4704, 256, 256), (
     dy = torch.randn(M, N, device="cuda"); dx = torch.empty(M, K, device="cuda")
     dw = torch.empty(N, K, device="cuda"); db = torch.empty(N, device="cuda")
     nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K); ws = torch.empty(nbytes // 4 + 4, device="cuda")
-    def dgrad(st): call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, precision(), c_void_p(st.cuda_stream))
+    def dgrad(st): call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, precision(), 0, c_void_p(st.cuda_stream))
     def wgrad(st): call("cswin_linear_bwd_weight", ptr(dy), ptr(x), None, 0, None, 1, ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, None, precision(), c_void_p(st.cuda_stream))
     def seq():
         cur = torch.cuda.current_stream()

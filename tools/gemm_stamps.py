@@ -14,9 +14,9 @@ dw = torch.empty(N, K, device="cuda"); db = torch.empty(N, device="cuda")
 nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K); ws = torch.empty(nbytes // 4 + 4, device="cuda")
 h = lib(); h.cswin_debug_set_stamps.argtypes = [ctypes.c_void_p]
 def run():
-    if mode == "fwd": call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, precision(), stream())
+    if mode == "fwd": call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, precision(), 0, stream())
     elif mode == "dw": call("cswin_linear_bwd_weight", ptr(dy), ptr(x), None, 0, None, 1, ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, None, precision(), stream())
-    else: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, precision(), stream())
+    else: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, precision(), 0, stream())
 for _ in range(3): run()
 torch.cuda.synchronize()
 h.cswin_debug_set_stamps(ctypes.c_void_p(st.data_ptr()))

@@ -13,15 +13,15 @@ def chain_buffers(M, C):
 
 def run_chain(b, w, M, C, bwd):
     s = stream()
-    call("cswin_linear_fwd", ptr(b["x"]), None, 0, ptr(w["qkv"]), ptr(w["bqkv"]), ptr(b["qkv"]), None, None, None, 1, M, 3 * C, C, precision(), s)
-    call("cswin_linear_fwd", ptr(b["att"]), None, 0, ptr(w["proj"]), ptr(w["bp"]), ptr(b["x1"]), None, ptr(b["x"]), None, 1, M, C, C, precision(), s)
-    call("cswin_linear_fwd", ptr(b["x1"]), None, 0, ptr(w["fc1"]), ptr(w["b1"]), ptr(b["pre"]), ptr(b["act"]), None, None, 1, M, 4 * C, C, precision(), s)
-    call("cswin_linear_fwd", ptr(b["act"]), None, 0, ptr(w["fc2"]), ptr(w["b2"]), ptr(b["y"]), None, ptr(b["x1"]), None, 1, M, C, 4 * C, precision(), s)
+    call("cswin_linear_fwd", ptr(b["x"]), None, 0, ptr(w["qkv"]), ptr(w["bqkv"]), ptr(b["qkv"]), None, None, None, 1, M, 3 * C, C, precision(), 0, s)
+    call("cswin_linear_fwd", ptr(b["att"]), None, 0, ptr(w["proj"]), ptr(w["bp"]), ptr(b["x1"]), None, ptr(b["x"]), None, 1, M, C, C, precision(), 0, s)
+    call("cswin_linear_fwd", ptr(b["x1"]), None, 0, ptr(w["fc1"]), ptr(w["b1"]), ptr(b["pre"]), ptr(b["act"]), None, None, 1, M, 4 * C, C, precision(), 0, s)
+    call("cswin_linear_fwd", ptr(b["act"]), None, 0, ptr(w["fc2"]), ptr(w["b2"]), ptr(b["y"]), None, ptr(b["x1"]), None, 1, M, C, 4 * C, precision(), 0, s)
     if bwd:
-        call("cswin_linear_bwd_data", ptr(b["dy"]), ptr(w["fc2"]), ptr(b["dpre"]), None, 0, ptr(b["pre"]), None, 1, None, M, C, 4 * C, precision(), s)
-        call("cswin_linear_bwd_data", ptr(b["dpre"]), ptr(w["fc1"]), ptr(b["dh"]), None, 0, None, None, 1, None, M, 4 * C, C, precision(), s)
-        call("cswin_linear_bwd_data", ptr(b["dh"]), ptr(w["proj"]), ptr(b["att"]), None, 0, None, None, 1, None, M, C, C, precision(), s)
-        call("cswin_linear_bwd_data", ptr(b["qkv"]), ptr(w["qkv"]), ptr(b["dh"]), None, 0, None, None, 1, None, M, 3 * C, C, precision(), s)
+        call("cswin_linear_bwd_data", ptr(b["dy"]), ptr(w["fc2"]), ptr(b["dpre"]), None, 0, ptr(b["pre"]), None, 1, None, M, C, 4 * C, precision(), 0, s)
+        call("cswin_linear_bwd_data", ptr(b["dpre"]), ptr(w["fc1"]), ptr(b["dh"]), None, 0, None, None, 1, None, M, 4 * C, C, precision(), 0, s)
+        call("cswin_linear_bwd_data", ptr(b["dh"]), ptr(w["proj"]), ptr(b["att"]), None, 0, None, None, 1, None, M, C, C, precision(), 0, s)
+        call("cswin_linear_bwd_data", ptr(b["qkv"]), ptr(w["qkv"]), ptr(b["dh"]), None, 0, None, None, 1, None, M, 3 * C, C, precision(), 0, s)
 
 def timed_graph(fn, reps=5):
     fn(); torch.cuda.synchronize()
@@ -57,7 +57,7 @@ for L, C in ((196, 256), (784, 128), (3136, 64)):
                     with torch.cuda.stream(st):
                         if OFFSET and si_ > 0:          # de-phase the chains: an extra half-size GEMM in front of the later streams
                             for _ in range(si_):
-                                call("cswin_linear_fwd", ptr(b["x"]), None, 0, ptr(w["proj"]), ptr(w["bp"]), ptr(b["dh"]), None, None, None, 1, Mp, C, C, precision(), stream())
+                                call("cswin_linear_fwd", ptr(b["x"]), None, 0, ptr(w["proj"]), ptr(w["bp"]), ptr(b["dh"]), None, None, None, 1, Mp, C, C, precision(), 0, stream())
                         for _ in range(10): run_chain(b, w, Mp, C, bwd)
                 for st in streams[1:]: main.wait_stream(st)
             return f

@@ -28,11 +28,11 @@ for name, M, N, K in shapes:
         H.cswin_debug_set_ws_gemm(on)
         y = torch.empty(M, N, device="cuda"); ya = torch.empty(M, N, device="cuda"); yr = torch.empty(M, N, device="cuda")
         dx = torch.empty(M, K, device="cuda"); dxg = torch.empty(M, K, device="cuda")
-        f_plain = lambda: call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, precision(), stream())
-        f_act = lambda: call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), ptr(ya), None, None, 1, M, N, K, precision(), stream())
-        f_res = lambda: call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(yr), None, ptr(res), ptr(rs), L, M, N, K, precision(), stream())
-        d_plain = lambda: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, precision(), stream())
-        d_gelu = lambda: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dxg), None, 0, ptr(pre), ptr(rs), L, None, M, N, K, precision(), stream())
+        f_plain = lambda: call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, precision(), 0, stream())
+        f_act = lambda: call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), ptr(ya), None, None, 1, M, N, K, precision(), 0, stream())
+        f_res = lambda: call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(yr), None, ptr(res), ptr(rs), L, M, N, K, precision(), 0, stream())
+        d_plain = lambda: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, precision(), 0, stream())
+        d_gelu = lambda: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dxg), None, 0, ptr(pre), ptr(rs), L, None, M, N, K, precision(), 0, stream())
         f_act(); f_res(); d_gelu()
         times[on] = (timed(f_plain), timed(d_plain))
         torch.cuda.synchronize()

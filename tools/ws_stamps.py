@@ -13,8 +13,8 @@ H.cswin_debug_set_ws_stamps.argtypes = [ctypes.c_void_p]
 x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda"); b = torch.randn(N, device="cuda")
 dy = torch.randn(M, N, device="cuda"); y = torch.empty(M, N, device="cuda"); dx = torch.empty(M, K, device="cuda")
 st = torch.zeros(512, 16, dtype=torch.int64, device="cuda")
-fn = (lambda: call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, precision(), stream())) if mode == "fwd" else \
-     (lambda: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, precision(), stream()))
+fn = (lambda: call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, precision(), 0, stream())) if mode == "fwd" else \
+     (lambda: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, precision(), 0, stream()))
 for _ in range(5): fn()
 torch.cuda.synchronize()
 H.cswin_debug_set_ws_stamps(ctypes.c_void_p(st.data_ptr()))
