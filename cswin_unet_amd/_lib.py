@@ -25,7 +25,7 @@ SIGNATURES = {
     "cswin_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, I, I, P, P, I, F, P, I, P]),
     "cswin_img2windows": (I, [P, P, I, I, I, I, I, I, P]),
     "cswin_windows2img": (I, [P, P, I, I, I, I, I, I, P]),
-    "cswin_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
+    "cswin_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, I, P]),
     "cswin_layernorm_bwd_workspace": (SZ, [I, I]),
     "cswin_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, P, P]),
     "cswin_linear_fwd": (I, [P, P, I, P, P, P, P, P, P, I, I, I, I, I, I, P]),
@@ -51,7 +51,7 @@ SIGNATURES = {
     "cswin_loss_finalize": (I, [P, P, P, D, I, F, F, P, P]),
     "cswin_loss_bwd": (I, [P, P, P, P, P, F, F, I, I, L, I, P]),
     "cswin_dropout": (I, [P, P, P, P, L, L, F, ctypes.c_ulonglong, P]),
-    "cswin_sgd_flat": (I, [P, P, P, L, P, F, F, F, P]),
+    "cswin_sgd_flat": (I, [P, P, P, L, P, F, F, F, P, P]),
     "cswin_multi_copy": (I, [P, I, P]),
     "cswin_pack_bf16": (I, [P, P, L, P]),
     "cswin_unpack_bf16": (I, [P, P, L, P]),
@@ -94,6 +94,36 @@ def set_act_bf16(on):
     prev = _state["act_bf16"]
     _state["act_bf16"] = bool(on)
     return prev
+
+
+# bf16 SHADOWS of fp32 weight buffers (optim.FlatSGD keeps one for its flat parameter buffer).  An entry: base address, bytes,
+# shadow tensor, refresh callback, {parameter address: tensor version when the shadow was last known to match}.
+_shadows = []
+
+
+def register_shadow(owner, shadow, refresh, params):
+    """`shadow` (bf16, same numel) mirrors the fp32 buffer `owner` that the tensors `params` alias.  The update kernel writes
+    both; a write from anywhere else (load_state_dict, a manual copy_) bumps the parameter's version counter, which
+    shadow_ptr() notices on the next use of that weight and answers with one refresh() of the whole shadow."""
+    _shadows[:] = [e for e in _shadows if e[0] != owner.data_ptr()]
+    params = list(params)
+    _shadows.append([owner.data_ptr(), owner.numel() * 4, shadow, refresh, {p.data_ptr(): p._version for p in params}, params])
+
+
+def shadow_ptr(w):
+    """Device address of the bf16 shadow of the fp32 weight tensor `w` (a registered parameter), or None."""
+    if not _shadows or w is None:
+        return None
+    a = w.data_ptr()
+    for base, nbytes, shadow, refresh, seen, params in _shadows:
+        if base <= a < base + nbytes:
+            if seen.get(a) != w._version:
+                refresh()
+                seen.clear()
+                seen.update({p.data_ptr(): p._version for p in params})
+                seen[a] = w._version
+            return c_void_p(shadow.data_ptr() + (a - base) // 2)
+    return None
 
 
 def set_precision(mode):

@@ -59,7 +59,8 @@ struct AttnParams {
     int ds_stride;         // fused backward: LDS row stride of the dS image (>= N, = 4 mod 8: conflict-free column writes)
     int slab_rows;         // LePE gradient slab rows per window (1 on every current path)
     long long* stamps;     // debug (cswin_debug_set_attn_stamps): [workgroup][8] s_memtime stamps of wave 0, or NULL
-    int qkv_bf16;          // qkv and dqkv are STORED as bf16 (bf16 activation storage); all arithmetic stays fp32
+    int qkv_bf16;          // storage mode: bit 0 = qkv and dqkv, bit 1 = y are STORED as bf16 (bf16 activation storage; 0, 1 or 3);
+                           // all arithmetic stays fp32
     AttnBranch br[2];
 };
 
@@ -80,6 +81,10 @@ __device__ __forceinline__ f32x4 qcv(f32x4 raw) { return raw; }
 __device__ __forceinline__ f32x4 qcv(u32x2 raw) {
     return f32x4{__builtin_bit_cast(float, raw[0] << 16), __builtin_bit_cast(float, raw[0] & 0xffff0000u),
                  __builtin_bit_cast(float, raw[1] << 16), __builtin_bit_cast(float, raw[1] & 0xffff0000u)};
+}
+template <bool Y16> __device__ __forceinline__ typename QRaw<Y16>::type ldy_raw(const AttnParams& p, const float* elem_ptr) {   // y (backward)
+    if constexpr (Y16) return *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(p.y_in) + (elem_ptr - p.y_in));
+    else return *reinterpret_cast<const f32x4*>(elem_ptr);
 }
 template <bool Q16> __device__ __forceinline__ f32x4 ldq(const AttnParams& p, const float* elem_ptr) { return qcv(ldq_raw<Q16>(p, elem_ptr)); }
 template <bool Q16> __device__ __forceinline__ void stdq(const AttnParams& p, float* elem_ptr, f32x4 v) {
@@ -201,8 +206,10 @@ __device__ __forceinline__ void lepe_wgrad_taps(const AttnBranch& br, const floa
 // QS = 2: the query tiles of a (window, head) are split over two workgroups (each stages the whole K / V stripe): with
 // 384 units on 256 CUs half the CUs would otherwise carry two whole units and set the kernel time; 768 half-units are
 // three per CU.  The two halves are `units` apart in the grid, i.e. on the same XCD / L2 when units % 8 == 0.
-template <int NT, int QS, bool Q16>
+template <int NT, int QS, int ST>
 __global__ __launch_bounds__(64 * (QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8))) void attn_fwd_kernel(AttnParams p, int units) {
+    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0;      // storage of qkv / dqkv and of y (see AttnParams)
+    (void)Q16; (void)Y16;
     constexpr int NP = 16 * NT;
     constexpr int NW = QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8);
     static_assert(QS == 1 || NT <= 8, "query split only for windows of up to 128 tokens");
@@ -336,7 +343,11 @@ __global__ __launch_bounds__(64 * (QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8))) 
                 f32x4 acc = *reinterpret_cast<const f32x4*>(&Wl[9 * HD + d0]);     // bias
                 acc = thin ? lepe_taps4<true, 1>(br, Vs, Wl, rr, cc, tq, d0, acc) : lepe_taps4<false, 1>(br, Vs, Wl, rr, cc, tq, d0, acc);
                 f32x4 out = o[df] * inv + acc;
-                if (d0 < p.hd) *reinterpret_cast<f32x4*>(p.y + ((long)w.b * L + lq) * p.C + ch0 + d0) = out;
+                if (d0 < p.hd) {
+                    const long yi = ((long)w.b * L + lq) * p.C + ch0 + d0;
+                    if constexpr (Y16) *reinterpret_cast<attn_bf16x4*>(reinterpret_cast<__bf16*>(p.y) + yi) = __builtin_convertvector(out, attn_bf16x4);
+                    else *reinterpret_cast<f32x4*>(p.y + yi) = out;
+                }
             }
             if (kq == 0) p.lse[((long)w.b * p.heads_total + br.head0 + w.g) * L + lq] = mx + __logf(sum);
         }
@@ -364,8 +375,10 @@ __device__ __forceinline__ float oct_sum(float v) {
 //       are the B operands as they stand); dS -> LDS.  The S / dP products of tile qt + 1 are issued before the VALU
 //       work of tile qt.  Then dV += LePE^T(dO), dK, dV -> global.
 //   P3  K fragments -> LDS over the dead Q image; dQ^T = K^T dS^T per query tile (one per wave) -> global.
-template <int NT, bool Q16>
+template <int NT, int ST>
 __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {      // 4 waves per SIMD: <= 128 VGPRs, two workgroups per CU at NT = 7
+    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0;      // storage of qkv / dqkv and of y (see AttnParams)
+    (void)Q16; (void)Y16;
     constexpr int NP = 16 * NT;
     constexpr int NTHREADS = 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -417,12 +430,12 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
     // P1 walks tokens t = 8 wave + (lane >> 3) + 8 NT j, j = 0, 1 (eight lanes per token, lane & 7 = 16-B channel chunk): its
     // y values, loaded now
     const int pc4 = lane & 7, ptg = lane >> 3;
-    f32x4 yv[2];
+    typename QRaw<Y16>::type yv[2];               // raw: widened where P1 consumes it
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int t = 8 * wave + ptg + 8 * NT * j;
-        yv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (t < N && 4 * pc4 < p.hd) yv[j] = *reinterpret_cast<const f32x4*>(y_b + (long)token_of(br, w, p.reso, t) * p.C + ch0 + 4 * pc4);
+        yv[j] = {};
+        if (t < N && 4 * pc4 < p.hd) yv[j] = ldy_raw<Y16>(p, y_b + (long)token_of(br, w, p.reso, t) * p.C + ch0 + 4 * pc4);
     }
     for (int t = tid; t < NP; t += NTHREADS) {
         lse_s[t] = t < N ? lse_b[token_of(br, w, p.reso, t)] : INFINITY;   // +inf -> P = 0 on padded query rows
@@ -489,7 +502,7 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
                     }
             }
             a4[9] += g4;
-            const f32x4 o4 = yv[j] - bias4 - lw4;
+            const f32x4 o4 = qcv(yv[j]) - bias4 - lw4;
             const float part = oct_sum(g4[0] * o4[0] + g4[1] * o4[1] + g4[2] * o4[2] + g4[3] * o4[3]);
             if (tv && pc4 == 0) del_s[t] = part;
         }
@@ -684,8 +697,10 @@ __device__ __forceinline__ int token_of2(const AttnBranch& br, int ih, int iw, i
 }
 
 // grid: ceil(B * L * heads_total / 32) blocks of 256 threads; 8 lanes per (token, head)
-template <bool Q16>
+template <int ST>
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
+    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0;      // storage of qkv / dqkv and of y (see AttnParams)
+    (void)Q16; (void)Y16;
     const int L = p.reso * p.reso, C3 = 3 * p.C;
     const long item = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
     const int j = threadIdx.x & 7;
@@ -717,7 +732,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
                     for (int e = 0; e < 4; ++e) lepe[e] += br.lepe_w[(cb + e) * 9 + tap] * v[e];
                 }
             }
-        const f32x4 yv = *reinterpret_cast<const f32x4*>(p.y_in + ((long)b * L + l) * p.C + ch0);
+        const f32x4 yv = qcv(ldy_raw<Y16>(p, p.y_in + ((long)b * L + l) * p.C + ch0));
         const f32x4 dv = *reinterpret_cast<const f32x4*>(p.dy + ((long)b * L + l) * p.C + ch0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) part += dv[e] * (yv[e] - lepe[e]);
@@ -731,8 +746,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
 }
 
 // one workgroup (4 waves) = 64 keys of one (branch, window, head); wave w owns keys [k0 + 16 w, +16)
-template <bool Q16>
+template <int ST>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk) {
+    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0;      // storage of qkv / dqkv and of y (see AttnParams)
+    (void)Q16; (void)Y16;
     __shared__ __attribute__((aligned(16))) float Qc[64 * LDT];
     __shared__ __attribute__((aligned(16))) float Dc[64 * LDT];
     __shared__ __attribute__((aligned(16))) float lse_c[64];
@@ -844,8 +861,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk
 }
 
 // one workgroup (4 waves) = 64 queries of one (branch, window, head); wave w owns queries [q0 + 16 w, +16)
-template <bool Q16>
+template <int ST>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk) {
+    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0;      // storage of qkv / dqkv and of y (see AttnParams)
+    (void)Q16; (void)Y16;
     __shared__ __attribute__((aligned(16))) float Kc[64 * LDT];
     __shared__ __attribute__((aligned(16))) float Vc[64 * LDT];
     const BigWg w = decode_big(p, blockIdx.x, nblk);
@@ -928,8 +947,10 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk)
 // only (L1 / L2 resident).  (The first version -- one thread per (token slot, channel), scalar loads -- took 69 us per launch
 // at 384 x 384, 8 % of that step.)
 constexpr int LW_SUB = 4;
-template <bool Q16>
+template <int ST>
 __global__ __launch_bounds__(256) void lepe_wgrad_kernel(AttnParams p) {
+    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0;      // storage of qkv / dqkv and of y (see AttnParams)
+    (void)Q16; (void)Y16;
     __shared__ __attribute__((aligned(16))) float red[16 * 8 * 4];
     const int sub = (int)blockIdx.x % LW_SUB;
     const WgInfo w = decode_wg(p, (int)blockIdx.x / LW_SUB);
@@ -1046,7 +1067,7 @@ int fill_params(AttnParams& p, const char* who, int B, int reso, int C, int nbra
     return CSWIN_OK;
 }
 
-template <int NT, bool Q16>
+template <int NT, int Q16>
 int launch_fwd_q(const AttnParams& p, int nwg, hipStream_t st) {
     constexpr int NW = NT < 8 ? NT : 8;
     const size_t lds = (size_t)(2 * 16 * NT * LDT + 10 * HD) * sizeof(float);
@@ -1073,7 +1094,7 @@ int launch_fwd_q(const AttnParams& p, int nwg, hipStream_t st) {
 
 template <int NT>
 int launch_fwd(const AttnParams& p, int nwg, hipStream_t st) {
-    return p.qkv_bf16 ? launch_fwd_q<NT, true>(p, nwg, st) : launch_fwd_q<NT, false>(p, nwg, st);
+    return p.qkv_bf16 == 3 ? launch_fwd_q<NT, 3>(p, nwg, st) : p.qkv_bf16 ? launch_fwd_q<NT, 1>(p, nwg, st) : launch_fwd_q<NT, 0>(p, nwg, st);
 }
 
 inline int ds_stride_for(int N) {            // smallest stride >= N with stride = 4 (mod 8): 16-B aligned rows, and the four
@@ -1082,7 +1103,7 @@ inline int ds_stride_for(int N) {            // smallest stride >= N with stride
     return s;
 }
 
-template <int NT, bool Q16>
+template <int NT, int Q16>
 int launch_bwd2_q(const AttnParams& p, int nwg, hipStream_t st) {
     constexpr int NP = 16 * NT;
     const int S = p.ds_stride;
@@ -1103,10 +1124,10 @@ int launch_bwd2_q(const AttnParams& p, int nwg, hipStream_t st) {
 
 template <int NT>
 int launch_bwd2(const AttnParams& p, int nwg, hipStream_t st) {
-    return p.qkv_bf16 ? launch_bwd2_q<NT, true>(p, nwg, st) : launch_bwd2_q<NT, false>(p, nwg, st);
+    return p.qkv_bf16 == 3 ? launch_bwd2_q<NT, 3>(p, nwg, st) : p.qkv_bf16 ? launch_bwd2_q<NT, 1>(p, nwg, st) : launch_bwd2_q<NT, 0>(p, nwg, st);
 }
 
-template <bool Q16>
+template <int Q16>
 void launch_bwd_two_pass(const AttnParams& p, long items, int nwg, int nblk, hipStream_t st) {
     hipLaunchKernelGGL(attn_delta_kernel<Q16>, dim3((unsigned)((items * 8 + 255) / 256)), dim3(256), 0, st, p);
     hipLaunchKernelGGL(attn_bwd_kv_kernel<Q16>, dim3(nwg * nblk), dim3(256), 0, st, p, nblk);
@@ -1134,7 +1155,8 @@ int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* co
                    int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split, float scale, int qkv_bf16,
                    void* stream) {
     AttnParams p = {};
-    p.qkv_bf16 = qkv_bf16 != 0;
+    CSWIN_REQUIRE(qkv_bf16 == 0 || qkv_bf16 == 1 || qkv_bf16 == 3, CSWIN_ERR_UNSUPPORTED, "attn: storage mode %d (0 = fp32, 1 = qkv / dqkv bf16, 3 = qkv / dqkv and y bf16)", qkv_bf16);
+    p.qkv_bf16 = qkv_bf16;
     int nt, nwg;
     int rc = fill_params(p, "attn_fwd", B, reso, C, nbranch, heads, idx, split, scale, &nt, &nwg);
     if (rc) return rc;
@@ -1176,7 +1198,8 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
                    void* workspace, size_t ws_bytes, int B, int reso, int C, int nbranch, const int* heads, const int* idx,
                    int split, float scale, cswin_reduce_job* deferred, int qkv_bf16, void* stream) {
     AttnParams p = {};
-    p.qkv_bf16 = qkv_bf16 != 0;
+    CSWIN_REQUIRE(qkv_bf16 == 0 || qkv_bf16 == 1 || qkv_bf16 == 3, CSWIN_ERR_UNSUPPORTED, "attn: storage mode %d (0 = fp32, 1 = qkv / dqkv bf16, 3 = qkv / dqkv and y bf16)", qkv_bf16);
+    p.qkv_bf16 = qkv_bf16;
     int nt, nwg;
     int rc = fill_params(p, "attn_bwd", B, reso, C, nbranch, heads, idx, split, scale, &nt, &nwg);
     if (rc) return rc;
@@ -1200,8 +1223,9 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
         // windows of more than 112 tokens (384x384: N = 144, 288): two-pass path
         const int N = p.br[0].H_sp * p.br[0].W_sp, nblk = (N + 63) / 64;
         const long items = (long)B * p.heads_total * reso * reso;
-        if (p.qkv_bf16) launch_bwd_two_pass<true>(p, items, nwg, nblk, st);
-        else launch_bwd_two_pass<false>(p, items, nwg, nblk, st);
+        if (p.qkv_bf16 == 3) launch_bwd_two_pass<3>(p, items, nwg, nblk, st);
+        else if (p.qkv_bf16) launch_bwd_two_pass<1>(p, items, nwg, nblk, st);
+        else launch_bwd_two_pass<0>(p, items, nwg, nblk, st);
         rc = CSWIN_OK;
     } else {
         switch (nt) {

@@ -26,6 +26,8 @@
 
 // wsgemm.hip: weight-stationary family for plain tall-skinny Linears (returns 1 when the shape is not served there)
 int cswin_ws_gemm(int mode, int epi_mode, const float* A, const float* W, const void* epilogue, int M, int N, int R, void* stream);
+// both operands stored as bf16 (gemm16.hip); 0 = launched, 1 = not covered
+int cswin_gemm16(int mode, int epi_mode, const void* A, const void* B, const void* epilogue, int M, int NO, int R, void* stream);
 // wgrad16.hip: bf16-operand weight gradients with transposing LDS reads (bf16 matmul mode)
 int cswin_wgrad16_batch(const cswin_wgrad_desc* d, int n, const int* splits, const int* rows_per_split, void* stream);
 
@@ -252,11 +254,11 @@ __device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Ep
     // register prefetch of the next tile: raw loads only -- nothing may consume pa/pb before stash(), or the
     // compiler waits for the loads in front of the MFMA section
     f32x4 pa[QA], pb[QB];
-    u32x2 pa16[QA];                                  // A stored as bf16: its raw chunks (pa is then unused)
+    u32x2 pa16[QA], pb16[QB];                        // an operand stored as bf16: its raw chunks (pa / pb is then unused)
     float pas[QA];
     // a16 (std::true_type / false_type): A is STORED as bf16.  A compile-time copy of the main loop per storage type: a run-time
     // choice between the 8-B and the 16-B load inside fetch() splits it into basic blocks and the loads end up waiting for one another.
-    auto fetch = [&](int r0, auto a16) {
+    auto fetch = [&](int r0, auto a16, auto b16) {
 #pragma unroll
         for (int q = 0; q < QA; ++q) {
             typename ASrc::Row rr;
@@ -301,8 +303,13 @@ __device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Ep
             }
             if (VEC == 4) {
                 const float* p = (!B_RC || j < r_end) ? B.ptr(rr, j) : nullptr;
-                pb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (p) pb[q] = *reinterpret_cast<const f32x4*>(p);
+                if constexpr (decltype(b16)::value) {
+                    pb16[q] = u32x2{0u, 0u};
+                    if (p) pb16[q] = src_load4_bf16(B, p);
+                } else {
+                    pb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (p) pb[q] = *reinterpret_cast<const f32x4*>(p);
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -312,7 +319,7 @@ __device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Ep
             }
         }
     };
-    auto stash = [&](auto a16) {
+    auto stash = [&](auto a16, auto b16) {
 #pragma unroll
         for (int q = 0; q < QA; ++q) {
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -350,8 +357,11 @@ __device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Ep
 #pragma unroll
         for (int q = 0; q < QB; ++q) {
             if constexpr (PREC == 1) {
+                u32x2 hb;                                // 4 bf16 as two dwords (stored bf16: unchanged bits)
+                if constexpr (decltype(b16)::value) hb = pb16[q];
+                else hb = __builtin_bit_cast(u32x2, __builtin_convertvector(pb[q], bf16x4));
                 if (B_RC) {
-                    *reinterpret_cast<bf16x4*>(&Bs16[(b_r + q * B_RPP) * LD16 + 4 * b_c]) = __builtin_convertvector(pb[q], bf16x4);
+                    *reinterpret_cast<u32x2*>(&Bs16[(b_r + q * B_RPP) * LD16 + 4 * b_c]) = hb;
                 } else {
                     // source rows run along the REDUCTION index (data gradient: W[r][k]): keep them as they arrive, [r][BN] bf16
                     // rows of 128 B, and let ds_read_b64_tr_b16 do the transpose when the fragments are read (below).  16-B
@@ -359,8 +369,7 @@ __device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Ep
                     // 32-lane half fall into 64 distinct banks.
                     static_assert(B_RC || BN == 64, "transposed-read B image is laid out for 64-column tiles");
                     const int row = b_r + q * B_RPP;
-                    *reinterpret_cast<bf16x4*>(&Bs16[row * BN + 8 * ((b_c >> 1) ^ (((row >> 1) & 1) << 2)) + 4 * (b_c & 1)]) =
-                        __builtin_convertvector(pb[q], bf16x4);
+                    *reinterpret_cast<u32x2*>(&Bs16[row * BN + 8 * ((b_c >> 1) ^ (((row >> 1) & 1) << 2)) + 4 * (b_c & 1)]) = hb;
                 }
             } else {
                 *reinterpret_cast<f32x4*>(&Bs[(b_r + q * B_RPP) * LDB + 4 * b_c]) = pb[q];
@@ -380,14 +389,14 @@ __device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Ep
     const bool do_colsum = !A_RC && epi.colsum && n0 == 0 && tid < BM;
 
     if (epi.stamps && tid == 0) { epi.stamps[8L * stamp_row + 0] = __builtin_amdgcn_s_memtime(); epi.stamps[8L * stamp_row + 4] = __builtin_amdgcn_s_getreg(6164); epi.stamps[8L * stamp_row + 5] = __builtin_amdgcn_s_memrealtime(); }
-    auto main_loop = [&](auto a16) {
-        fetch(r_begin, a16);
-        stash(a16);
+    auto main_loop = [&](auto a16, auto b16) {
+        fetch(r_begin, a16, b16);
+        stash(a16, b16);
         __syncthreads();
         if (epi.stamps && tid == 0) epi.stamps[8L * stamp_row + 1] = __builtin_amdgcn_s_memtime();
         for (int r0 = r_begin; r0 < r_end; r0 += BK) {
             const bool more = r0 + BK < r_end;
-            if (more) fetch(r0 + BK, a16);
+            if (more) fetch(r0 + BK, a16, b16);
             if (do_colsum) {
                 if constexpr (PREC == 1) {
 #pragma unroll 8
@@ -463,17 +472,26 @@ __device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Ep
             }
             __syncthreads();
             if (more) {
-                stash(a16);
+                stash(a16, b16);
                 __syncthreads();
             }
         }
     };
     if (r_begin < r_end) {
-        if constexpr (PREC == 1 && A_RC && VEC == 4 && std::is_same<ASrc, PlainSrc>::value) {
-            if (src_is_bf16(A)) main_loop(std::true_type{});
-            else main_loop(std::false_type{});
+        // storage variants (bf16 mode, forward / data-gradient Linears only): A (activations) and / or B (the weights' bf16 shadow)
+        constexpr bool CAN_A16 = PREC == 1 && A_RC && VEC == 4 && std::is_same<ASrc, PlainSrc>::value;
+        constexpr bool CAN_B16 = PREC == 1 && A_RC && VEC == 4 && std::is_same<BSrc, PlainSrc>::value;
+        const bool a_is16 = CAN_A16 && src_is_bf16(A), b_is16 = CAN_B16 && src_is_bf16(B);
+        if constexpr (CAN_A16 && CAN_B16) {
+            if (a_is16 && b_is16) main_loop(std::true_type{}, std::true_type{});
+            else if (a_is16) main_loop(std::true_type{}, std::false_type{});
+            else if (b_is16) main_loop(std::false_type{}, std::true_type{});
+            else main_loop(std::false_type{}, std::false_type{});
+        } else if constexpr (CAN_B16) {
+            if (b_is16) main_loop(std::false_type{}, std::true_type{});
+            else main_loop(std::false_type{}, std::false_type{});
         } else {
-            main_loop(std::false_type{});
+            main_loop(std::false_type{}, std::false_type{});
         }
     }
 
@@ -662,8 +680,8 @@ int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* 
                      float* y_act, const float* residual, const float* row_scale, int rows_per_sample, int M, int N,
                      int K, int precision, int io_bf16, void* stream) {
     CSWIN_CHECK_PRECISION(precision, "linear_fwd");
-    CSWIN_REQUIRE(io_bf16 == 0 || (precision == 1 && !x2 && (io_bf16 & ~3) == 0 && K % 4 == 0 && N % 4 == 0 && !((io_bf16 & 2) && residual)), CSWIN_ERR_UNSUPPORTED,
-                  "linear_fwd: bf16 storage (io_bf16 = %d: 1 = x, 2 = y / y_act) needs precision 1, a plain input, K and N multiples of 4; a residual output stays fp32", io_bf16);
+    CSWIN_REQUIRE(io_bf16 == 0 || (precision == 1 && (!x2 || !(io_bf16 & 1)) && (io_bf16 & ~7) == 0 && K % 4 == 0 && N % 4 == 0 && !((io_bf16 & 2) && residual)), CSWIN_ERR_UNSUPPORTED,
+                  "linear_fwd: bf16 storage (io_bf16 = %d: 1 = x, 2 = y / y_act, 4 = w) needs precision 1, a plain input for bit 1, K and N multiples of 4; a residual output stays fp32", io_bf16);
     CSWIN_REQUIRE(x && w && y && M > 0 && N > 0 && K > 0, CSWIN_ERR_SHAPE, "linear_fwd: bad arguments M=%d N=%d K=%d", M, N, K);
     CSWIN_REQUIRE(!x2 || (k_split > 0 && k_split < K), CSWIN_ERR_SHAPE, "linear_fwd: bad concat split %d of K=%d", k_split, K);
     CSWIN_REQUIRE(!row_scale || rows_per_sample > 0, CSWIN_ERR_SHAPE, "linear_fwd: rows_per_sample must be > 0");
@@ -674,13 +692,14 @@ int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* 
     e.residual = residual; e.ldres = N;
     e.row_scale = row_scale; e.rows_per_sample = rows_per_sample;
     e.c_bf16 = (io_bf16 & 2) != 0;
-    PlainSrc B = {w, K, N, K, nullptr, 1};
+    PlainSrc B = {w, K, N, K, nullptr, 1, (io_bf16 >> 2) & 1};
     CSWIN_REQUIRE(!(y_act && residual), CSWIN_ERR_UNSUPPORTED, "linear_fwd: activation and residual epilogues are exclusive");
     const int rk = cdiv(K, BKMAX) * BKMAX;
     if (x2) {
         CSWIN_REQUIRE(!y_act, CSWIN_ERR_UNSUPPORTED, "linear_fwd: concat input does not support the activation epilogue");
         ConcatSrc A = {x, x2, k_split, K - k_split, M, K, k_split};
         bool vec = (k_split % 4 == 0) && (K % 4 == 0) && aligned16(x) && aligned16(x2) && aligned16(w);
+        CSWIN_REQUIRE(io_bf16 == 0 || (io_bf16 == 4 && vec), CSWIN_ERR_UNSUPPORTED, "linear_fwd: a concat input takes only the bf16 weight flag (4), with 16-B aligned operands");
         if (residual) {
             if (vec) launch_gemm<true, true, 4, EPI_RES, false>(A, B, e, M, N, K, 1, rk, precision, st);
             else launch_gemm<true, true, 1, EPI_RES, false>(A, B, e, M, N, K, 1, rk, precision, st);
@@ -693,6 +712,12 @@ int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* 
             const int rc = cswin_ws_gemm(0, y_act ? EPI_ACT : (residual ? EPI_RES : EPI_PLAIN), x, w, &e, M, N, K, stream);
             if (rc < 0) return rc;
             if (rc == 0) {
+                CSWIN_LAUNCH_CHECK();
+                return CSWIN_OK;
+            }
+        }
+        if (precision == 1 && (io_bf16 & 5) == 5) {             // both operands stored as bf16: LDS-DMA kernel (gemm16.hip)
+            if (cswin_gemm16(0, y_act ? EPI_ACT : (residual ? EPI_RES : EPI_PLAIN), x, w, &e, M, N, K, stream) == 0) {
                 CSWIN_LAUNCH_CHECK();
                 return CSWIN_OK;
             }
@@ -721,8 +746,8 @@ int cswin_linear_bwd_data(const float* dy, const float* w, float* dx, float* dx2
                           const float* row_scale, int rows_per_sample, const float* add, int M, int N, int K,
                           int precision, int io_bf16, void* stream) {
     CSWIN_CHECK_PRECISION(precision, "linear_bwd_data");
-    CSWIN_REQUIRE(io_bf16 == 0 || (precision == 1 && !dx2 && !add && (io_bf16 & ~11) == 0 && K % 4 == 0 && N % 4 == 0), CSWIN_ERR_UNSUPPORTED,
-                  "linear_bwd_data: bf16 storage (io_bf16 = %d: 1 = dy, 2 = dx, 8 = gelu_pre) needs precision 1, no split / add, K and N multiples of 4", io_bf16);
+    CSWIN_REQUIRE(io_bf16 == 0 || (precision == 1 && ((!dx2 && !add) || (io_bf16 & ~4) == 0) && (io_bf16 & ~15) == 0 && K % 4 == 0 && N % 4 == 0), CSWIN_ERR_UNSUPPORTED,
+                  "linear_bwd_data: bf16 storage (io_bf16 = %d: 1 = dy, 2 = dx, 4 = w, 8 = gelu_pre) needs precision 1, K and N multiples of 4; split / add outputs take only the weight flag", io_bf16);
     CSWIN_REQUIRE(dy && w && dx && M > 0 && N > 0 && K > 0, CSWIN_ERR_SHAPE, "linear_bwd_data: bad arguments");
     CSWIN_REQUIRE(!dx2 || (k_split > 0 && k_split < K), CSWIN_ERR_SHAPE, "linear_bwd_data: bad concat split");
     CSWIN_REQUIRE(!row_scale || rows_per_sample > 0, CSWIN_ERR_SHAPE, "linear_bwd_data: rows_per_sample must be > 0");
@@ -737,7 +762,7 @@ int cswin_linear_bwd_data(const float* dy, const float* w, float* dx, float* dx2
     CSWIN_REQUIRE(io_bf16 == 0 || (aligned16(dy) && aligned16(w) && aligned16(dx) && (!gelu_pre || aligned16(gelu_pre))), CSWIN_ERR_ALIGN,
                   "linear_bwd_data: bf16 storage needs 16-B aligned operands");
     PlainSrc A = {dy, N, M, N, nullptr, 1, io_bf16 & 1};
-    PlainSrc B = {w, K, N, K, nullptr, 1};     // S(i = n (reduction), j = k): row-contiguous image
+    PlainSrc B = {w, K, N, K, nullptr, 1, (io_bf16 >> 2) & 1};     // S(i = n (reduction), j = k): row-contiguous image
     bool vec = (N % 4 == 0) && (K % 4 == 0) && aligned16(dy) && aligned16(w);
     // output rows = M, output cols = K, reduction = N
     const int rn = cdiv(N, BKMAX) * BKMAX;
@@ -747,6 +772,12 @@ int cswin_linear_bwd_data(const float* dy, const float* w, float* dx, float* dx2
         const int rc = cswin_ws_gemm(1, gelu_pre ? EPI_GELUBWD : (add ? EPI_RES : EPI_PLAIN), dy, w, &e, M, K, N, stream);
         if (rc < 0) return rc;
         if (rc == 0) {
+            CSWIN_LAUNCH_CHECK();
+            return CSWIN_OK;
+        }
+    }
+    if (precision == 1 && !dx2 && !add && (io_bf16 & 5) == 5) {  // both operands stored as bf16: LDS-DMA kernel (gemm16.hip)
+        if (cswin_gemm16(1, gelu_pre ? EPI_GELUBWD : EPI_PLAIN, dy, w, &e, M, K, N, stream) == 0) {
             CSWIN_LAUNCH_CHECK();
             return CSWIN_OK;
         }

@@ -1,0 +1,200 @@
+// Forward and data-gradient Linears of the bf16 mode whose BOTH operands are stored as bf16 (activations: cswin_linear_fwd /
+// cswin_linear_bwd_data io_bf16 bit 0; weights: the optimiser's bf16 shadow, io_bf16 bit 2), gfx950 / CDNA4.
+//
+//   forward      : C[m][n] = sum_k A[m][k] W[n][k]       (cswin_unet.py:169,177,23-27 nn.Linear; A (M, K), W (N, K))
+//   data gradient: C[m][k] = sum_n A[m][n] W[n][k]       (its autograd backward;          A = dy (M, N), W (N, K))
+//
+// With bf16 MFMAs (v_mfma_f32_32x32x16_bf16: 16x the fp32 rate) a 64 x 64 x 64 step of the tiled family (gemm.hip) holds 128
+// cycles of matrix work and costs ~1800: one global-load round trip per step, because its register prefetch reaches one step
+// ahead and the data then still has to be converted and written to LDS (profiles/round2_notes.md, in-kernel stamps).
+// Operands that are ALREADY bf16 in memory need neither: here every step's tiles travel global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, no VGPRs, no ds_write), up to four steps in flight per workgroup -- the whole K = 256 panel of the
+// C x C and C x 3C Linears is requested before the first MFMA --, and the only per-step synchronisation is one counted
+// s_waitcnt vmcnt + s_barrier.
+//
+// LDS images (per step and operand: 64 rows x 128 B, written by the DMA in lane order, so the XOR swizzles are applied to the
+// SOURCE addresses):
+//   A, and W of the forward (rows = output column n, 64 reduction values each): 16-B chunk c of row r sits in slot c ^ ((r >> 1) & 7);
+//     the MFMA fragments are ds_read_b128 (8 reduction values of one row), conflict free.
+//   W of the data gradient (rows = reduction index n, 64 output columns k each): slot c ^ (4 * ((r >> 1) & 1)), the image gemm.hip
+//     uses for its transposing reads (ds_read_b64_tr_b16 delivers the reduction-contiguous fragments).
+// One workgroup = 4 waves = one 64 x 64 output tile (wave: 32 x 32); epilogue shared with the tiled family (gemm_epilogue.h).
+#include <mutex>
+#include <type_traits>
+#include "common.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+typedef __bf16 g16_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short g16_s16x4 __attribute__((ext_vector_type(4)));
+typedef short g16_s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) g16_s16x4 g16_lds_s16x4;
+
+constexpr int G16_T = 64;                 // tile edge (rows, columns) and reduction step
+constexpr int G16_IMG = G16_T * 128;      // bytes of one operand image of one step
+constexpr int G16_STAGE = 2 * G16_IMG;
+
+struct G16Params {
+    const __bf16* A; long lda;            // (M, R) rows
+    const __bf16* B; long ldb;            // forward: (NO, R) rows;  data gradient: (R, NO) rows
+    int M, NO, R;                         // output rows / columns, reduction length (a multiple of 64)
+    int tiles_m, tiles_n, nblk;
+    Epilogue epi;
+};
+
+// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to lds_dst + 16 * lane (lds_dst wave-uniform).  hipcc does not count
+// these loads; completion is tracked by hand (g16_wait) -- nothing else in the main loop touches vmcnt.
+__device__ __forceinline__ void g16_dma(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void g16_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void g16_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// S: LDS stages = steps in flight (2 .. 4).  BT: data gradient (W rows run along the reduction index).
+template <int EPI, bool BT, int S, bool PRE16>
+__global__ __launch_bounds__(256) void gemm16_kernel(G16Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char g16_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    // XCD-aware block order (as gemm.hip): each XCD takes a contiguous range of tiles, ordered [m-tile][n-tile]
+    const int bid = blockIdx.x, xq = p.nblk >> 3, xr = p.nblk & 7, xcd = bid & 7;
+    const int lb = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int m0 = (lb / p.tiles_n) * G16_T, n0 = (lb % p.tiles_n) * G16_T;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int nsteps = p.R / G16_T;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)g16_lds;   // LDS byte address of the ring
+
+    // ---- DMA source addresses: wave w moves row groups 2w and 2w + 1 (8 rows each) of both images of a step ----
+    const int drow = lane >> 3, slot = lane & 7;
+    const unsigned char* a_src[2];
+    const unsigned char* b_src[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int row = (2 * wave + g) * 8 + drow;                       // row of the image
+        const int ca = slot ^ ((row >> 1) & 7);                          // source chunk of this lane's slot
+        const int am = min(m0 + row, p.M - 1);                           // clamped rows are never stored
+        a_src[g] = reinterpret_cast<const unsigned char*>(p.A + (long)am * p.lda + 8 * ca);
+        if (!BT) {
+            const int bn = min(n0 + row, p.NO - 1);
+            b_src[g] = reinterpret_cast<const unsigned char*>(p.B + (long)bn * p.ldb + 8 * ca);
+        } else {
+            int cb = slot ^ (((row >> 1) & 1) << 2);
+            cb = min(cb, (p.NO - n0) / 8 - 1);                           // columns beyond NO: any in-range chunk (never stored)
+            b_src[g] = reinterpret_cast<const unsigned char*>(p.B + (long)row * p.ldb + n0 + 8 * cb);
+        }
+    }
+    auto issue = [&](int step) {
+        const unsigned st = lds0 + (unsigned)(step % S) * G16_STAGE + (unsigned)wave * 2048;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) g16_dma(a_src[g] + (long)step * (G16_T * 2), st + g * 1024);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const unsigned char* src = BT ? b_src[g] + (long)step * G16_T * p.ldb * 2 : b_src[g] + (long)step * (G16_T * 2);
+            g16_dma(src, st + G16_IMG + g * 1024);
+        }
+    };
+
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.f;
+
+    for (int s = 0; s < S - 1 && s < nsteps; ++s) issue(s);
+    for (int step = 0; step < nsteps; ++step) {
+        // this step's 4 DMAs (per wave) have landed when at most 4 * (groups issued after it) are outstanding
+        const int later = min(S - 2, nsteps - 1 - step);
+        if (S >= 4 && later >= 2) g16_wait<8>();
+        else if (S >= 3 && later >= 1) g16_wait<4>();
+        else g16_wait<0>();
+        g16_barrier();                     // every wave's part of the step is in LDS; the stage read in step - 1 is free again
+        if (step + S - 1 < nsteps) issue(step + S - 1);
+        const unsigned char* aimg = g16_lds + (step % S) * G16_STAGE;
+        const unsigned char* bimg = aimg + G16_IMG;
+#pragma unroll
+        for (int kk = 0; kk < G16_T; kk += 16) {
+            const int c = (kk >> 3) + lh;                                 // 16-B chunk of this lane's 8 reduction values
+            const int ar = wm0 + li;
+            const g16_bf16x8 af = *reinterpret_cast<const g16_bf16x8*>(aimg + ar * 128 + 16 * (c ^ ((ar >> 1) & 7)));
+            g16_bf16x8 bf;
+            if (!BT) {
+                const int br = wn0 + li;
+                bf = *reinterpret_cast<const g16_bf16x8*>(bimg + br * 128 + 16 * (c ^ ((br >> 1) & 7)));
+            } else {
+                // lane (q, p) of its 16-lane group supplies row r + q, columns c0 + 4 p .. + 3; it receives column c0 + (lane & 15) of
+                // rows r .. r + 3: two reads give the 8 reduction values of this lane's output column (gemm.hip, same image)
+                const int col = wn0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+                const int row = kk + 8 * lh + ((lane & 15) >> 2);
+                const int sw = ((row >> 1) & 1) << 2;                     // rows row and row + 4 share bit 1
+                const unsigned char* a0 = bimg + row * 128 + 16 * ((col >> 3) ^ sw) + 2 * (col & 7);
+                const g16_s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((g16_lds_s16x4*)a0);
+                const g16_s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((g16_lds_s16x4*)(a0 + 4 * 128));
+                const g16_s16x8 f = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                bf = __builtin_bit_cast(g16_bf16x8, f);
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[0][0], 0, 0, 0);
+        }
+    }
+    g16_barrier();                          // the stage ring becomes the epilogue's per-wave transpose patches
+    run_epilogue<EPI, 1, 1, PRE16>(p.epi, acc, p.M, p.NO, m0 + wm0, n0 + wn0, lane, reinterpret_cast<float*>(g16_lds) + wave * EP_WAVE_FLOATS,
+                                   p.epi.vec_store != 0);
+}
+
+template <int EPI, bool BT, bool PRE16>
+int g16_launch(const G16Params& p, hipStream_t st) {
+    const int nsteps = p.R / G16_T;
+    static const int forced = getenv("CSWIN_GEMM16_STAGES") ? atoi(getenv("CSWIN_GEMM16_STAGES")) : 0;      // tuning aid: 2 .. 4
+    int S = nsteps >= 4 ? 4 : (nsteps == 3 ? 3 : 2);
+    if (forced >= 2 && forced <= 4) S = forced;
+    const size_t lds = (size_t)S * G16_STAGE;
+    static_assert(2 * G16_STAGE >= 4 * EP_WAVE_FLOATS * (int)sizeof(float), "the ring must hold the epilogue patches");
+    // dynamic-LDS opt-in of the three instantiations: once per process, thread-safe (a function attribute, not a stream operation)
+    static std::once_flag once;
+    static hipError_t status = hipSuccess;
+    std::call_once(once, [&] {
+        status = hipFuncSetAttribute((const void*)gemm16_kernel<EPI, BT, 4, PRE16>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G16_STAGE);
+        if (status == hipSuccess) status = hipFuncSetAttribute((const void*)gemm16_kernel<EPI, BT, 3, PRE16>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * G16_STAGE);
+    });
+    if (status != hipSuccess) return 1;
+    if (S == 4) hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 4, PRE16>), dim3(p.nblk), dim3(256), lds, st, p);
+    else if (S == 3) hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 3, PRE16>), dim3(p.nblk), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 2, PRE16>), dim3(p.nblk), dim3(256), lds, st, p);
+    return 0;
+}
+
+}  // namespace
+
+// Internal entry used by gemm.hip's cswin_linear_fwd / cswin_linear_bwd_data (precision 1, io_bf16 bits 0 and 2 both set, plain
+// single-source forms).  mode 0: forward (A (M, R), B (NO, R));  mode 1: data gradient (A (M, R), B (R, NO)).
+// Returns 0 when launched, 1 when the shape is not covered (the caller falls back to the tiled family).
+int cswin_gemm16(int mode, int epi_mode, const void* A, const void* B, const void* epilogue, int M, int NO, int R, void* stream) {
+    static const bool off = getenv("CSWIN_GEMM16") && atoi(getenv("CSWIN_GEMM16")) == 0;                    // tuning aid
+    if (off || R % G16_T != 0 || NO % 8 != 0 || M < 1) return 1;
+    if ((((uintptr_t)A) | ((uintptr_t)B)) & 15) return 1;
+    G16Params p;
+    p.A = (const __bf16*)A; p.lda = R;
+    p.B = (const __bf16*)B; p.ldb = mode == 0 ? R : NO;
+    p.M = M; p.NO = NO; p.R = R;
+    p.tiles_m = cdiv(M, G16_T); p.tiles_n = cdiv(NO, G16_T);
+    p.nblk = p.tiles_m * p.tiles_n;
+    p.epi = *(const Epilogue*)epilogue;
+    p.epi.vec_store = epilogue_vec_ok(p.epi, NO);
+    p.epi.stamps = nullptr;
+    if (!p.epi.vec_store) return 1;          // bf16-stored outputs / auxiliaries need the 16-B epilogue path anyway
+    hipStream_t st = (hipStream_t)stream;
+    const bool pre16 = p.epi.pre_bf16 != 0;
+    if (mode == 0) {
+        switch (epi_mode) {
+            case EPI_PLAIN: return g16_launch<EPI_PLAIN, false, false>(p, st);
+            case EPI_ACT: return g16_launch<EPI_ACT, false, false>(p, st);
+            case EPI_RES: return g16_launch<EPI_RES, false, false>(p, st);
+            default: return 1;
+        }
+    }
+    switch (epi_mode) {
+        case EPI_PLAIN: return g16_launch<EPI_PLAIN, true, false>(p, st);
+        case EPI_GELUBWD: return pre16 ? g16_launch<EPI_GELUBWD, true, true>(p, st) : g16_launch<EPI_GELUBWD, true, false>(p, st);
+        default: return 1;
+    }
+}

@@ -6,12 +6,19 @@
 
 namespace {
 
+// y may be STORED as bf16 (bf16 activation storage: the output feeds only GEMMs, which round it to bf16 anyway)
+typedef __bf16 ln_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ln_store4(float* y, long idx, f32x4 v, int y_bf16) {
+    if (y_bf16) *reinterpret_cast<ln_bf16x4*>(reinterpret_cast<__bf16*>(y) + idx) = __builtin_convertvector(v, ln_bf16x4);
+    else *reinterpret_cast<f32x4*>(y + idx) = v;
+}
+
 // LPR lanes cooperate on one row, each holding VPL float4 (C = 4 * LPR * VPL)
 template <int LPR, int VPL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float* __restrict__ y,
                                                       float* __restrict__ mean, float* __restrict__ rstd, int M,
-                                                      float eps) {
+                                                      float eps, int y_bf16) {
     constexpr int C = 4 * LPR * VPL;
     constexpr int RPB = 256 / LPR;                    // rows per block pass
     const int sub = threadIdx.x % LPR, rib = threadIdx.x / LPR;
@@ -48,7 +55,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             f32x4 o4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o4[e] = (xv[v][e] - mu) * rs * g[v][e] + b[v][e];
-            *reinterpret_cast<f32x4*>(y + row * C + 4 * (sub + v * LPR)) = o4;
+            ln_store4(y, row * C + 4 * (sub + v * LPR), o4, y_bf16);
         }
         if (sub == 0) {
             mean[row] = mu;
@@ -134,7 +141,7 @@ constexpr int GEN_MAXV = 4;     // chunks per lane kept in registers: C <= 4 * 6
 __global__ __launch_bounds__(256) void ln_fwd_generic_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ y,
                                                               float* __restrict__ mean, float* __restrict__ rstd, int M, int C,
-                                                              float eps) {
+                                                              float eps, int y_bf16) {
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, nchunk = C >> 2;
     for (long row = (long)blockIdx.x * 4 + wib; row < M; row += (long)gridDim.x * 4) {
         f32x4 xv[GEN_MAXV];
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(256) void ln_fwd_generic_kernel(const float* __rest
                 f32x4 o4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o4[e] = (xv[v][e] - mu) * rs * g[e] + b[e];
-                *reinterpret_cast<f32x4*>(y + row * C + 4 * ch) = o4;
+                ln_store4(y, row * C + 4 * ch, o4, y_bf16);
             }
         }
         if (lane == 0) {
@@ -239,8 +246,8 @@ int ln_grid(int M, int rpb) { return min(cdiv(M, rpb), 512); }
 
 template <int LPR, int VPL>
 void launch_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int M, float eps,
-                hipStream_t st) {
-    hipLaunchKernelGGL((ln_fwd_kernel<LPR, VPL>), dim3(ln_grid(M, 256 / LPR)), dim3(256), 0, st, x, g, b, y, mean, rstd, M, eps);
+                int y_bf16, hipStream_t st) {
+    hipLaunchKernelGGL((ln_fwd_kernel<LPR, VPL>), dim3(ln_grid(M, 256 / LPR)), dim3(256), 0, st, x, g, b, y, mean, rstd, M, eps, y_bf16);
 }
 template <int LPR, int VPL>
 void launch_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* g,
@@ -256,22 +263,23 @@ bool ln_supported(int C) { return C > 0 && C % 4 == 0 && C <= 256 * GEN_MAXV; }
 extern "C" {
 
 int cswin_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                        int M, int C, float eps, void* stream) {
+                        int M, int C, float eps, int y_bf16, void* stream) {
     CSWIN_REQUIRE(x && gamma && beta && y && mean && rstd && M > 0, CSWIN_ERR_SHAPE, "layernorm_fwd: bad arguments");
+    y_bf16 = y_bf16 != 0;
     CSWIN_REQUIRE(ln_supported(C), CSWIN_ERR_UNSUPPORTED, "layernorm: C=%d must be a multiple of 4, at most 1024", C);
     hipStream_t st = (hipStream_t)stream;
     if (!ln_fast(C)) {
-        hipLaunchKernelGGL(ln_fwd_generic_kernel, dim3(ln_grid(M, 4)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, C, eps);
+        hipLaunchKernelGGL(ln_fwd_generic_kernel, dim3(ln_grid(M, 4)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, C, eps, y_bf16);
         CSWIN_LAUNCH_CHECK();
         return CSWIN_OK;
     }
     switch (C) {
-        case 32: launch_fwd<8, 1>(x, gamma, beta, y, mean, rstd, M, eps, st); break;
-        case 64: launch_fwd<16, 1>(x, gamma, beta, y, mean, rstd, M, eps, st); break;
-        case 128: launch_fwd<32, 1>(x, gamma, beta, y, mean, rstd, M, eps, st); break;
-        case 256: launch_fwd<64, 1>(x, gamma, beta, y, mean, rstd, M, eps, st); break;
-        case 512: launch_fwd<64, 2>(x, gamma, beta, y, mean, rstd, M, eps, st); break;
-        case 1024: launch_fwd<64, 4>(x, gamma, beta, y, mean, rstd, M, eps, st); break;
+        case 32: launch_fwd<8, 1>(x, gamma, beta, y, mean, rstd, M, eps, y_bf16, st); break;
+        case 64: launch_fwd<16, 1>(x, gamma, beta, y, mean, rstd, M, eps, y_bf16, st); break;
+        case 128: launch_fwd<32, 1>(x, gamma, beta, y, mean, rstd, M, eps, y_bf16, st); break;
+        case 256: launch_fwd<64, 1>(x, gamma, beta, y, mean, rstd, M, eps, y_bf16, st); break;
+        case 512: launch_fwd<64, 2>(x, gamma, beta, y, mean, rstd, M, eps, y_bf16, st); break;
+        case 1024: launch_fwd<64, 4>(x, gamma, beta, y, mean, rstd, M, eps, y_bf16, st); break;
     }
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;

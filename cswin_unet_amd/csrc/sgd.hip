@@ -9,7 +9,8 @@ namespace {
 
 __global__ __launch_bounds__(256) void sgd_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, long n, const float* __restrict__ lr_dev,
-                                                        float momentum, float wd, float grad_scale) {
+                                                        float momentum, float wd, float grad_scale, __bf16* __restrict__ shadow) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     const float lr = lr_dev[0];
     const long n4 = n / 4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -20,11 +21,14 @@ __global__ __launch_bounds__(256) void sgd_flat_kernel(float* __restrict__ p, co
         pv -= lr * mv;
         reinterpret_cast<f32x4*>(p)[i] = pv;
         reinterpret_cast<f32x4*>(m)[i] = mv;
+        if (shadow) reinterpret_cast<bf16x4*>(shadow)[i] = __builtin_convertvector(pv, bf16x4);     // the GEMMs' bf16 copy of the weights
     }
     for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float mv = momentum * m[i] + (g[i] * grad_scale + wd * p[i]);
         m[i] = mv;
-        p[i] -= lr * mv;
+        const float pn = p[i] - lr * mv;
+        p[i] = pn;
+        if (shadow) shadow[i] = (__bf16)pn;
     }
 }
 
@@ -85,12 +89,13 @@ int cswin_unpack_bf16(const void* src, float* dst, long n, void* stream) {
 }
 
 int cswin_sgd_flat(float* p, const float* g, float* m, long n, const float* lr_dev, float momentum, float weight_decay,
-                   float grad_scale, void* stream) {
+                   float grad_scale, void* shadow_bf16, void* stream) {
     CSWIN_REQUIRE(p && g && m && lr_dev && n > 0, CSWIN_ERR_SHAPE, "sgd_flat: bad arguments");
     CSWIN_REQUIRE(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m)) & 15) == 0, CSWIN_ERR_ALIGN, "sgd_flat: buffers must be 16-B aligned");
+    CSWIN_REQUIRE(!shadow_bf16 || (((uintptr_t)shadow_bf16) & 7) == 0, CSWIN_ERR_ALIGN, "sgd_flat: the bf16 shadow must be 8-B aligned");
     long b = (n / 4 + 255) / 256;
     int grid = (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
-    hipLaunchKernelGGL(sgd_flat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, n, lr_dev, momentum, weight_decay, grad_scale);
+    hipLaunchKernelGGL(sgd_flat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, n, lr_dev, momentum, weight_decay, grad_scale, (__bf16*)shadow_bf16);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }

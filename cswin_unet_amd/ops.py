@@ -10,7 +10,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from ._lib import ReduceJob, WgradDesc, act_bf16, call, dev_f32, lib, precision, ptr, stream
+from ._lib import ReduceJob, WgradDesc, act_bf16, call, dev_f32, lib, precision, ptr, shadow_ptr, stream
 
 __all__ = ["layer_norm", "linear", "linear_pair", "mlp", "stripe_attention", "cswin_block", "conv_tokens", "patch_embed_conv", "carafe_reassemble",
            "tokens_to_nchw", "matmul_nn", "ce_dice_loss", "dropout", "img2windows", "windows2img"]
@@ -96,7 +96,7 @@ class _LayerNorm(Function):
         y = torch.empty_like(x)
         mean = torch.empty(M, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        call("cswin_layernorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), M, C, eps, stream())
+        call("cswin_layernorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), M, C, eps, 0, stream())
         ctx.save_for_backward(x, gamma, mean, rstd)
         return y
 
@@ -128,6 +128,17 @@ def _rows_per_sample(x):
     return x.numel() // (x.shape[0] * x.shape[-1])
 
 
+def _wsrc(w):
+    """(pointer, io_bf16 bits) of a Linear weight for cswin_linear_fwd / _bwd_data: in the bf16 mode with bf16 storage, the bf16
+    shadow the optimiser keeps of it (bit 2) when there is one -- same values as the GEMM's own rounding, half the bytes --,
+    else the fp32 tensor."""
+    if act_bf16() and w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0:
+        sp = shadow_ptr(w)
+        if sp is not None:
+            return sp, 4
+    return ptr(w), 0
+
+
 class _Linear(Function):
     @staticmethod
     def forward(ctx, x, w, b, x2, residual, row_scale):
@@ -140,8 +151,9 @@ class _Linear(Function):
         M = x.numel() // K1
         y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
         rps = _rows_per_sample(x) if row_scale is not None else 1
-        call("cswin_linear_fwd", ptr(x), ptr(x2), K1 if x2 is not None else 0, ptr(w), ptr(b), ptr(y), None, ptr(residual),
-             ptr(row_scale), rps, M, N, K, precision(), 0, stream())
+        pw, fw = _wsrc(w)
+        call("cswin_linear_fwd", ptr(x), ptr(x2), K1 if x2 is not None else 0, pw, ptr(b), ptr(y), None, ptr(residual),
+             ptr(row_scale), rps, M, N, K, precision(), fw, stream())
         ctx.save_for_backward(x, w, x2, row_scale)
         ctx.has_bias, ctx.has_res, ctx.rps = b is not None, residual is not None, rps
         return y
@@ -159,8 +171,9 @@ class _Linear(Function):
         if need[0] or (x2 is not None and need[3]):
             dx = torch.empty_like(x)
             dx2 = torch.empty_like(x2) if x2 is not None else None
-            call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), ptr(dx2), K1 if x2 is not None else 0, None,
-                 ptr(row_scale), ctx.rps, None, M, N, K, precision(), 0, stream())
+            pw, fw = _wsrc(w)
+            call("cswin_linear_bwd_data", ptr(dy), pw, ptr(dx), ptr(dx2), K1 if x2 is not None else 0, None,
+                 ptr(row_scale), ctx.rps, None, M, N, K, precision(), fw, stream())
         if need[1]:
             with _side_stream(dy, x, x2, row_scale):
                 dw = torch.empty_like(w)
@@ -248,17 +261,18 @@ class _Mlp(Function):
         M = x.numel() // K
         pre = torch.empty(x.shape[:-1] + (Hd,), dtype=torch.float32, device=x.device)
         act = torch.empty_like(pre)
-        call("cswin_linear_fwd", ptr(x), None, 0, ptr(w1), ptr(b1), ptr(pre), ptr(act), None, None, 1, M, Hd, K, precision(), 0, stream())
+        (p1, f1), (p2, f2) = _wsrc(w1), _wsrc(w2)
+        call("cswin_linear_fwd", ptr(x), None, 0, p1, ptr(b1), ptr(pre), ptr(act), None, None, 1, M, Hd, K, precision(), f1, stream())
         y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
         rps = _rows_per_sample(x) if row_scale is not None else 1
         if drop_p > 0:
             call("cswin_dropout", ptr(act), None, None, ptr(act), act.numel(), act.numel() // act.shape[0], drop_p, seeds[0], stream())
-            call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(b2), ptr(y), None, None, None, 1, M, N, Hd, precision(), 0, stream())
+            call("cswin_linear_fwd", ptr(act), None, 0, p2, ptr(b2), ptr(y), None, None, None, 1, M, N, Hd, precision(), f2, stream())
             call("cswin_dropout", ptr(y), ptr(residual), ptr(row_scale), ptr(y), y.numel(), y.numel() // y.shape[0], drop_p, seeds[1],
                  stream())
         else:
-            call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(b2), ptr(y), None, ptr(residual), ptr(row_scale), rps,
-                 M, N, Hd, precision(), 0, stream())
+            call("cswin_linear_fwd", ptr(act), None, 0, p2, ptr(b2), ptr(y), None, ptr(residual), ptr(row_scale), rps,
+                 M, N, Hd, precision(), f2, stream())
         ctx.save_for_backward(x, w1, w2, pre, act, row_scale)
         ctx.has_res, ctx.rps, ctx.has_b1, ctx.has_b2 = residual is not None, rps, b1 is not None, b2 is not None
         ctx.drop = (float(drop_p), seeds)
@@ -418,27 +432,31 @@ class _CSWinBlock(Function):
         lb = [dev_f32(t) for t in lepe[nb:]]
         rs1, rs2 = dev_f32(rs1), dev_f32(rs2)
         E = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
-        # bf16 mode: the tensors that only GEMMs and the attention kernel read -- qkv, the MLP hidden pair and (backward) their
-        # gradients -- are STORED as bf16 (the largest tensors of a block: 3C and 2 x 4C wide); everything else stays fp32
+        # bf16 mode: every tensor of the block that only GEMMs and the attention kernel read -- both LayerNorm outputs, qkv, the
+        # attention output, the MLP hidden pair and (backward) the gradients of qkv and the hidden layer -- is STORED as bf16, and
+        # the GEMMs read the weights' bf16 shadow (_wsrc).  The residual stream (x, x1, y), its gradients, the LayerNorm / softmax
+        # statistics, master weights and every accumulation stay fp32.
         s16 = act_bf16() and C % 4 == 0
         E16 = (lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=dev)) if s16 else E
-        h1, m1, r1 = torch.empty_like(x), E(M), E(M)
-        call("cswin_layernorm_fwd", ptr(x), ptr(g1), ptr(b1), ptr(h1), ptr(m1), ptr(r1), M, C, eps1, st)
+        (pq, fq), (pp, fp), (p1, f1), (p2, f2) = [_wsrc(w) if s16 else (ptr(w), 0) for w in (wqkv, wp, w1, w2)]
+        io_x, io_xy = (1, 3) if s16 else (0, 0)                       # input / input and output stored as bf16
+        h1, m1, r1 = E16(B, L, C), E(M), E(M)
+        call("cswin_layernorm_fwd", ptr(x), ptr(g1), ptr(b1), ptr(h1), ptr(m1), ptr(r1), M, C, eps1, int(s16), st)
         qkv = E16(B, L, 3 * C)
-        call("cswin_linear_fwd", ptr(h1), None, 0, ptr(wqkv), ptr(bqkv), ptr(qkv), None, None, None, 1, M, 3 * C, C, precision(), 2 if s16 else 0, st)
-        att, lse = E(B, L, C), E(B, sum(heads), L)
+        call("cswin_linear_fwd", ptr(h1), None, 0, pq, ptr(bqkv), ptr(qkv), None, None, None, 1, M, 3 * C, C, precision(), io_xy | fq, st)
+        att, lse = E16(B, L, C), E(B, sum(heads), L)
         ha, ia = _int_array(heads), _int_array(idx)
         call("cswin_attn_fwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(att), ptr(lse), B, reso, C, nb, ha, ia, split,
-             float(scale or 0.0), int(s16), st)
+             float(scale or 0.0), 3 if s16 else 0, st)
         x1 = torch.empty_like(x)
-        call("cswin_linear_fwd", ptr(att), None, 0, ptr(wp), ptr(bp), ptr(x1), None, ptr(x), ptr(rs1), L, M, C, C, precision(), 0, st)
-        h2, m2, r2 = torch.empty_like(x), E(M), E(M)
-        call("cswin_layernorm_fwd", ptr(x1), ptr(g2), ptr(b2), ptr(h2), ptr(m2), ptr(r2), M, C, eps2, st)
+        call("cswin_linear_fwd", ptr(att), None, 0, pp, ptr(bp), ptr(x1), None, ptr(x), ptr(rs1), L, M, C, C, precision(), io_x | fp, st)
+        h2, m2, r2 = E16(B, L, C), E(M), E(M)
+        call("cswin_layernorm_fwd", ptr(x1), ptr(g2), ptr(b2), ptr(h2), ptr(m2), ptr(r2), M, C, eps2, int(s16), st)
         Hd = w1.shape[0]
         pre, act = E16(B, L, Hd), E16(B, L, Hd)
-        call("cswin_linear_fwd", ptr(h2), None, 0, ptr(w1), ptr(bb1), ptr(pre), ptr(act), None, None, 1, M, Hd, C, precision(), 2 if s16 else 0, st)
+        call("cswin_linear_fwd", ptr(h2), None, 0, p1, ptr(bb1), ptr(pre), ptr(act), None, None, 1, M, Hd, C, precision(), io_xy | f1, st)
         y = torch.empty_like(x)
-        call("cswin_linear_fwd", ptr(act), None, 0, ptr(w2), ptr(bb2), ptr(y), None, ptr(x1), ptr(rs2), L, M, C, Hd, precision(), 1 if s16 else 0, st)
+        call("cswin_linear_fwd", ptr(act), None, 0, p2, ptr(bb2), ptr(y), None, ptr(x1), ptr(rs2), L, M, C, Hd, precision(), io_x | f2, st)
         ctx.save_for_backward(x, m1, r1, h1, qkv, lse, att, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lw, *lb)
         ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0), bqkv is not None, s16)
         return y
@@ -464,9 +482,10 @@ class _CSWinBlock(Function):
         wsp = [ctypes.c_void_p(ws.data_ptr() + sum(sizes[:i])) for i in range(6)]
         jobs = (ReduceJob * 8)()
         J = lambda i: ctypes.cast(ctypes.byref(jobs[i]), ctypes.c_void_p)
+        (pq, fq), (pp, fp), (p1, f1), (p2, f2) = [_wsrc(w) if s16 else (ptr(w), 0) for w in (wqkv, wp, w1, w2)]
         # ---- MLP branch ----
         dpre = torch.empty_like(pre)
-        call("cswin_linear_bwd_data", ptr(dy), ptr(w2), ptr(dpre), None, 0, ptr(pre), ptr(rs2), L, None, M, C, Hd, precision(), 10 if s16 else 0, st)
+        call("cswin_linear_bwd_data", ptr(dy), p2, ptr(dpre), None, 0, ptr(pre), ptr(rs2), L, None, M, C, Hd, precision(), (10 if s16 else 0) | f2, st)
         # the four weight gradients are off the critical path: they run as ONE batched launch once all operands exist
         wg = (WgradDesc * 4)()
 
@@ -480,17 +499,17 @@ class _CSWinBlock(Function):
         dw2, db2 = torch.empty_like(w2), E(C)
         defer_wgrad(0, dy, act, rs2, dw2, db2, 0, C, Hd, io=2)          # x = act is stored as bf16
         dw1, db1 = torch.empty_like(w1), E(Hd)
-        defer_wgrad(1, dpre, h2, None, dw1, db1, 1, Hd, C, io=1)        # dy = dpre is stored as bf16
-        dh2 = torch.empty_like(x)
-        call("cswin_linear_bwd_data", ptr(dpre), ptr(w1), ptr(dh2), None, 0, None, None, 1, None, M, Hd, C, precision(), 1 if s16 else 0, st)
+        defer_wgrad(1, dpre, h2, None, dw1, db1, 1, Hd, C, io=3)        # dy = dpre and x = h2 are stored as bf16
+        dh2 = torch.empty_like(x)                                      # fp32 (x is)
+        call("cswin_linear_bwd_data", ptr(dpre), p1, ptr(dh2), None, 0, None, None, 1, None, M, Hd, C, precision(), (1 if s16 else 0) | f1, st)
         dx1, dg2, dbt2 = torch.empty_like(x), E(C), E(C)
         call("cswin_layernorm_bwd", ptr(dh2), ptr(x1), ptr(m2), ptr(r2), ptr(g2), ptr(dy), ptr(dx1), ptr(dg2), ptr(dbt2), wsp[2],
              sizes[2], M, C, J(2), st)
         # ---- attention branch ----
         datt = dh2                                                     # reuse
-        call("cswin_linear_bwd_data", ptr(dx1), ptr(wp), ptr(datt), None, 0, None, ptr(rs1), L, None, M, C, C, precision(), 0, st)
+        call("cswin_linear_bwd_data", ptr(dx1), pp, ptr(datt), None, 0, None, ptr(rs1), L, None, M, C, C, precision(), fp, st)
         dwp, dbp = torch.empty_like(wp), E(C)
-        defer_wgrad(2, dx1, att, rs1, dwp, dbp, 3, C, C)
+        defer_wgrad(2, dx1, att, rs1, dwp, dbp, 3, C, C, io=2)          # x = att is stored as bf16
         early = None
         if _overlap["block"]:
             # fc2, fc1 and proj weight gradients have all their operands now: they run BESIDE the attention backward
@@ -508,10 +527,10 @@ class _CSWinBlock(Function):
         naw = h.cswin_attn_bwd_workspace(B, reso, C, nb, ha, ia, split)
         aws = _ws(naw, dev)
         call("cswin_attn_bwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(lse), ptr(att), ptr(datt), ptr(dqkv),
-             _ptr_array(dlw), _ptr_array(dlb), ptr(aws), naw, B, reso, C, nb, ha, ia, split, scale, J(6), int(s16), st)
+             _ptr_array(dlw), _ptr_array(dlb), ptr(aws), naw, B, reso, C, nb, ha, ia, split, scale, J(6), 3 if s16 else 0, st)
         dwqkv = torch.empty_like(wqkv)
         dbqkv = E(3 * C) if has_qkv_bias else None
-        defer_wgrad(3, dqkv, h1, None, dwqkv, dbqkv, 4, 3 * C, C, io=1)  # dy = dqkv is stored as bf16
+        defer_wgrad(3, dqkv, h1, None, dwqkv, dbqkv, 4, 3 * C, C, io=3)  # dy = dqkv and x = h1 are stored as bf16
         wjobs = (ReduceJob * 4)()
         if early is not None:
             call("cswin_linear_bwd_weight_batch", ctypes.cast(ctypes.byref(wg[3]), ctypes.c_void_p), 1,
@@ -523,7 +542,7 @@ class _CSWinBlock(Function):
         for slot, ji in enumerate((0, 1, 3, 4)):
             jobs[ji] = wjobs[slot]
         dh1 = datt                                                     # reuse again
-        call("cswin_linear_bwd_data", ptr(dqkv), ptr(wqkv), ptr(dh1), None, 0, None, None, 1, None, M, 3 * C, C, precision(), 1 if s16 else 0, st)
+        call("cswin_linear_bwd_data", ptr(dqkv), pq, ptr(dh1), None, 0, None, None, 1, None, M, 3 * C, C, precision(), (1 if s16 else 0) | fq, st)
         dx, dg1, dbt1 = torch.empty_like(x), E(C), E(C)
         call("cswin_layernorm_bwd", ptr(dh1), ptr(x), ptr(m1), ptr(r1), ptr(g1), ptr(dx1), ptr(dx), ptr(dg1), ptr(dbt1), wsp[5],
              sizes[5], M, C, J(5), st)

@@ -1,6 +1,6 @@
 """SGD(momentum, weight_decay) of the reference's training loop (trainer.py:42,60-63) on flat buffers.
 
-All parameters are re-pointed into ONE flat fp32 buffer (16-B aligned slots), momentum and gradients
+All parameters are re-pointed into ONE flat fp32 buffer (32-B aligned slots), momentum and gradients
 live in two more.  A step is two launches: a multi-tensor gather of the per-parameter .grad tensors
 into the flat gradient buffer (the buffer RCCL all-reduces, in buckets, under data parallelism) and
 one fused update kernel.  The learning rate lives in device memory so that a captured hipGraph can be
@@ -9,7 +9,7 @@ replayed under the poly schedule.
 import numpy as np
 import torch
 
-from ._lib import call, ptr, stream
+from ._lib import call, ptr, register_shadow, stream
 
 _CHUNK = 16384      # floats per gather workgroup
 
@@ -26,7 +26,7 @@ class FlatSGD:
         self.offsets, off = [], 0
         for p in self.params:
             self.offsets.append(off)
-            off += (p.numel() + 3) // 4 * 4
+            off += (p.numel() + 7) // 8 * 8          # 32-B slots: the bf16 shadow of every parameter is 16-B aligned as well
         self.numel = off
         self.flat_param = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -36,6 +36,11 @@ class FlatSGD:
                 view = self.flat_param[o:o + p.numel()].view(p.shape)
                 view.copy_(p.data)
                 p.data = view                       # parameters now alias the flat buffer
+        # bf16 working copy of the weights for the bf16 matmul mode (the Linears read it instead of rounding the fp32 master
+        # weights in every GEMM); written by the update kernel, re-packed when something else writes the parameters
+        self.flat_param16 = torch.empty(off, dtype=torch.bfloat16, device=dev)
+        self.refresh_shadow()
+        register_shadow(self.flat_param, self.flat_param16, self.refresh_shadow, self.params)
         self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
         self.lr = float(lr)
         # gather tables: one {src, dst, n} record per <= 16 Ki-float chunk, per gathered parameter range
@@ -56,7 +61,7 @@ class FlatSGD:
     def flat_range(self, first, last):
         """[lo, hi) element range of the flat buffers covered by parameters first..last-1."""
         lo = self.offsets[first]
-        hi = self.offsets[last - 1] + (self.params[last - 1].numel() + 3) // 4 * 4
+        hi = self.offsets[last - 1] + (self.params[last - 1].numel() + 7) // 8 * 8
         return lo, hi
 
     def _gather_table(self, first, last):
@@ -97,7 +102,10 @@ class FlatSGD:
     def apply(self, grad_scale=1.0):
         """p, m <- SGD(flat_grad * grad_scale) (one launch)."""
         call("cswin_sgd_flat", ptr(self.flat_param), ptr(self.flat_grad), ptr(self.flat_mom), self.numel, ptr(self.lr_dev),
-             self.momentum, self.weight_decay, float(grad_scale), stream())
+             self.momentum, self.weight_decay, float(grad_scale), ptr(self.flat_param16), stream())
+
+    def refresh_shadow(self):
+        call("cswin_pack_bf16", ptr(self.flat_param), ptr(self.flat_param16), self.numel, stream())
 
     def step(self, grad_scale=1.0):
         self.gather_grads()

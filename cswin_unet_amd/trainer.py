@@ -300,6 +300,8 @@ class DataParallelTrainer:
         self.collectives = self.world > 1 or (force_collectives and group is not None)
         if self.collectives:                    # identical replicas: rank 0's initial weights everywhere
             dist.broadcast(self.engine.flat_param, src=0, group=group)
+            if hasattr(self.engine, "opt"):
+                self.engine.opt.refresh_shadow()        # the broadcast wrote the flat buffer directly (no parameter version moves)
 
     @property
     def stats(self):

@@ -72,8 +72,10 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
                    const float* y, const float* dy, float* dqkv, float* const* dlepe_w, float* const* dlepe_b,
                    void* workspace, size_t ws_bytes, int B, int reso, int C, int nbranch, const int* heads, const int* idx,
                    int split, float scale, cswin_reduce_job* deferred, int qkv_bf16, void* stream);
-/* qkv_bf16 != 0: qkv (and dqkv) are STORED as bf16 -- the output format of cswin_linear_fwd(io_bf16 bit 1) --; the arithmetic of
- * the attention kernels stays fp32. */
+/* qkv_bf16: storage mode of both attention entry points.  0: every tensor fp32.  1: qkv (and dqkv) are STORED as bf16 -- the
+ * output format of cswin_linear_fwd(io_bf16 bit 1).  3: additionally y (the forward output, re-read by the backward) is stored
+ * as bf16 -- the input format of the proj Linear's io_bf16 bit 0.  dy, lse and the LePE parameters / gradients are fp32; the
+ * arithmetic of the attention kernels stays fp32. */
 
 /* ---- img2windows / windows2img (cswin_unet.py:184-202): index-only, bit-exact ----
  * img (B, C, H, W) -> out (B*nH*nW, H_sp*W_sp, C);   win (B*nH*nW, H_sp*W_sp, C) -> out (B, H, W, C) */
@@ -82,7 +84,9 @@ int cswin_windows2img(const float* win, float* out, int B, int C, int H, int W, 
 
 /* ---- nn.LayerNorm over C (cswin_unet.py:168,179,218,341,497,533); C in {32,64,128,256,512,1024} ---- */
 int cswin_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                        int M, int C, float eps, void* stream);
+                        int M, int C, float eps, int y_bf16, void* stream);
+/* y_bf16 != 0: y is STORED as bf16 (bf16 activation storage: the input format of cswin_linear_fwd io_bf16 bit 0 and of
+ * cswin_wgrad_desc io_bf16 bit 1); mean / rstd stay fp32. */
 size_t cswin_layernorm_bwd_workspace(int M, int C);
 /* dx = dres (optional residual-path gradient, may alias dx) + LN backward; dgamma/dbeta overwritten (by the returned
  * job when `deferred` is given, immediately otherwise) */
@@ -99,8 +103,12 @@ int cswin_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
 int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* w, const float* bias, float* y,
                      float* y_act, const float* residual, const float* row_scale, int rows_per_sample, int M, int N,
                      int K, int precision, int io_bf16, void* stream);
-/* io_bf16 (precision 1 only; 0 = every tensor fp32): activations STORED as bf16 in HBM, fp32 accumulation as before.
- *   cswin_linear_fwd:      bit 0 = x, bit 1 = y and y_act;     cswin_linear_bwd_data: bit 0 = dy, bit 1 = dx, bit 3 = gelu_pre.
+/* io_bf16 (precision 1 only; 0 = every tensor fp32): tensors STORED as bf16 in HBM, fp32 accumulation as before.
+ *   cswin_linear_fwd:      bit 0 = x, bit 1 = y and y_act, bit 2 = w;
+ *   cswin_linear_bwd_data: bit 0 = dy, bit 1 = dx, bit 2 = w, bit 3 = gelu_pre.
+ * Bit 2 reads the weights' bf16 SHADOW (same [N][K] layout; cswin_sgd_flat keeps it current): the GEMM rounds fp32 weights
+ * to bf16 while staging them anyway, so results are bit-identical and the weight traffic halves.  Concat / split / add
+ * forms accept bit 2 only.
  * dx (M, K) = add + row_scale * ((dy (M, N) @ w (N, K)) * gelu'(gelu_pre));  columns >= k_split go to dx2 if given */
 int cswin_linear_bwd_data(const float* dy, const float* w, float* dx, float* dx2, int k_split, const float* gelu_pre,
                           const float* row_scale, int rows_per_sample, const float* add, int M, int N, int K,
@@ -184,7 +192,9 @@ int cswin_loss_bwd(const float* logits, const long long* labels, const float* co
 
 /* ---- optimiser: torch.optim.SGD(momentum, weight_decay) (trainer.py:42,60) on one flat buffer ---- */
 int cswin_sgd_flat(float* p, const float* g, float* m, long n, const float* lr_dev, float momentum,
-                   float weight_decay, float grad_scale, void* stream);
+                   float weight_decay, float grad_scale, void* shadow_bf16, void* stream);
+/* shadow_bf16: NULL, or n bf16 that receive the updated parameters rounded to nearest even (the bf16 mode's working copy of
+ * the fp32 master weights, read by the Linears' io_bf16 bit 2). */
 /* table: device array of {const float* src; float* dst; long long n;} (24-byte records), one workgroup each */
 int cswin_multi_copy(const void* table, int nchunks, void* stream);
 

@@ -21,7 +21,7 @@ def chain(B, n, st):
     s = torch.cuda.current_stream().cuda_stream if st is None else st.cuda_stream
     import ctypes
     for _ in range(n):
-        call("cswin_layernorm_fwd", ptr(B["x"]), ptr(B["g"]), ptr(B["b"]), ptr(B["y"]), ptr(B["m"]), ptr(B["r"]), B["rows"], 256, 1e-5,
+        call("cswin_layernorm_fwd", ptr(B["x"]), ptr(B["g"]), ptr(B["b"]), ptr(B["y"]), ptr(B["m"]), ptr(B["r"]), B["rows"], 256, 1e-5, 0,
              ctypes.c_void_p(s))
 
 
