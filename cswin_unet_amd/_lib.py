@@ -27,7 +27,7 @@ SIGNATURES = {
     "cswin_windows2img": (I, [P, P, I, I, I, I, I, I, P]),
     "cswin_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, I, P]),
     "cswin_layernorm_bwd_workspace": (SZ, [I, I]),
-    "cswin_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, P, P]),
+    "cswin_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, P, P, P]),
     "cswin_linear_fwd": (I, [P, P, I, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "cswin_linear_bwd_data": (I, [P, P, P, P, I, P, P, I, P, I, I, I, I, I, P]),
     "cswin_linear_bwd_weight_workspace": (SZ, [I, I, I]),

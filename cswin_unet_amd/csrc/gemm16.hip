@@ -97,9 +97,35 @@ __global__ __launch_bounds__(256) void gemm16_kernel(G16Params p) {
         }
     };
 
-    f32x16 acc[1][1];
+    // ---- epilogue operands, requested BEFORE the first DMA (older in the in-order vmcnt queue, so the counted waits below are
+    // unaffected): bias, row factors and the residual / GELU' rows of this lane's store positions (row erow + 8 p, columns ecol..+3)
+    const Epilogue& e = p.epi;
+    const int erow = lane >> 3, ecol = n0 + wn0 + (lane & 7) * 4;
+    const bool ecol_ok = ecol < p.NO;
+    f32x4 bias_v = {0.f, 0.f, 0.f, 0.f};
+    if (e.bias && ecol_ok) bias_v = *reinterpret_cast<const f32x4*>(e.bias + ecol);
+    float rs[4];
+    f32x4 aux[4];
+    u32x2 aux16[4];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.f;
+    for (int q = 0; q < 4; ++q) {
+        const int m = m0 + wm0 + erow + 8 * q;
+        const bool ok = m < p.M && ecol_ok;
+        rs[q] = (e.row_scale && ok) ? e.row_scale[m / e.rows_per_sample] : 1.0f;
+        aux[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        aux16[q] = u32x2{0u, 0u};
+        if (EPI == EPI_RES && ok) aux[q] = *reinterpret_cast<const f32x4*>(e.residual + (long)m * e.ldres + ecol);
+        if (EPI == EPI_GELUBWD && ok) {
+            if constexpr (PRE16) aux16[q] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(e.gelu_pre) + (long)m * e.ldpre + ecol);
+            else aux[q] = *reinterpret_cast<const f32x4*>(e.gelu_pre + (long)m * e.ldpre + ecol);
+        }
+    }
+
+    f32x16 acc0, acc1;                    // two independent MFMA chains (alternate 16-k chunks), summed before the epilogue
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+    long long* stamps = e.stamps;            // debug (cswin_debug_set_stamps): the tiled family's record layout
+    if (stamps && tid == 0) { stamps[8L * bid + 0] = __builtin_amdgcn_s_memtime(); stamps[8L * bid + 4] = __builtin_amdgcn_s_getreg(6164); stamps[8L * bid + 5] = __builtin_amdgcn_s_memrealtime(); }
 
     for (int s = 0; s < S - 1 && s < nsteps; ++s) issue(s);
     for (int step = 0; step < nsteps; ++step) {
@@ -110,6 +136,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(G16Params p) {
         else g16_wait<0>();
         g16_barrier();                     // every wave's part of the step is in LDS; the stage read in step - 1 is free again
         if (step + S - 1 < nsteps) issue(step + S - 1);
+        if (stamps && tid == 0 && step == 0) stamps[8L * bid + 1] = __builtin_amdgcn_s_memtime();
         const unsigned char* aimg = g16_lds + (step % S) * G16_STAGE;
         const unsigned char* bimg = aimg + G16_IMG;
 #pragma unroll
@@ -133,19 +160,49 @@ __global__ __launch_bounds__(256) void gemm16_kernel(G16Params p) {
                 const g16_s16x8 f = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 bf = __builtin_bit_cast(g16_bf16x8, f);
             }
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[0][0], 0, 0, 0);
+            if ((kk >> 4) & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc1, 0, 0, 0);
+            else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc0, 0, 0, 0);
         }
     }
+    if (stamps && tid == 0) stamps[8L * bid + 2] = __builtin_amdgcn_s_memtime();
     g16_barrier();                          // the stage ring becomes the epilogue's per-wave transpose patches
-    run_epilogue<EPI, 1, 1, PRE16>(p.epi, acc, p.M, p.NO, m0 + wm0, n0 + wn0, lane, reinterpret_cast<float*>(g16_lds) + wave * EP_WAVE_FLOATS,
-                                   p.epi.vec_store != 0);
+    // ---- epilogue (the vector path of gemm_epilogue.h's run_epilogue for one 32 x 32 fragment, operands already in registers):
+    // C/D layout (lane = column, registers = rows) -> private [32][36] LDS patch -> lane owns 4 consecutive columns of 4 rows
+    acc0 += acc1;
+    float* wbuf = reinterpret_cast<float*>(g16_lds) + wave * EP_WAVE_FLOATS;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) wbuf[((g & 3) + 8 * (g >> 2) + 4 * lh) * EP_LD + li] = acc0[g];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = m0 + wm0 + erow + 8 * q;
+        if (m >= p.M || !ecol_ok) continue;
+        f32x4 o = *reinterpret_cast<const f32x4*>(&wbuf[(erow + 8 * q) * EP_LD + (lane & 7) * 4]) + bias_v;
+        if (EPI == EPI_GELUBWD) {
+            const f32x4 pre = PRE16 ? widen_bf16x4(aux16[q]) : aux[q];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] *= gelu_grad_f(pre[c]);
+        }
+        o *= rs[q];
+        if (EPI == EPI_RES) o += aux[q];
+        epi_store4(e.C, (long)m * e.ldc + ecol, o, e.c_bf16);
+        if (EPI == EPI_ACT) {
+            f32x4 a;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[c] = gelu_f(o[c]);
+            epi_store4(e.Cact, (long)m * e.ldact + ecol, a, e.c_bf16);
+        }
+    }
+    if (stamps && tid == 0) { stamps[8L * bid + 3] = __builtin_amdgcn_s_memtime(); stamps[8L * bid + 6] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 template <int EPI, bool BT, bool PRE16>
 int g16_launch(const G16Params& p, hipStream_t st) {
     const int nsteps = p.R / G16_T;
     static const int forced = getenv("CSWIN_GEMM16_STAGES") ? atoi(getenv("CSWIN_GEMM16_STAGES")) : 0;      // tuning aid: 2 .. 4
-    int S = nsteps >= 4 ? 4 : (nsteps == 3 ? 3 : 2);
+    int S = nsteps >= 3 ? 3 : 2;          // 48 KB: three workgroups per CU (measured against 2 and 4 stages: profiles/round2_notes.md)
     if (forced >= 2 && forced <= 4) S = forced;
     const size_t lds = (size_t)S * G16_STAGE;
     static_assert(2 * G16_STAGE >= 4 * EP_WAVE_FLOATS * (int)sizeof(float), "the ring must hold the epilogue patches");
@@ -180,8 +237,8 @@ int cswin_gemm16(int mode, int epi_mode, const void* A, const void* B, const voi
     p.nblk = p.tiles_m * p.tiles_n;
     p.epi = *(const Epilogue*)epilogue;
     p.epi.vec_store = epilogue_vec_ok(p.epi, NO);
-    p.epi.stamps = nullptr;
     if (!p.epi.vec_store) return 1;          // bf16-stored outputs / auxiliaries need the 16-B epilogue path anyway
+    if (p.epi.rm_on || p.epi.C2 || p.epi.colsum || p.epi.split_stride) return 1;      // forms the kernel's own epilogue does not implement
     hipStream_t st = (hipStream_t)stream;
     const bool pre16 = p.epi.pre_bf16 != 0;
     if (mode == 0) {

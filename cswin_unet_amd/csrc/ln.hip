@@ -69,7 +69,8 @@ template <int LPR, int VPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ dres,
-                                                      float* __restrict__ dx, float* __restrict__ partial, int M) {
+                                                      float* __restrict__ dx, float* __restrict__ partial, int M,
+                                                      __bf16* __restrict__ dx16) {
     constexpr int C = 4 * LPR * VPL;
     constexpr int RPB = 256 / LPR;
     __shared__ float red[2 * RPB * C];
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             for (int e = 0; e < 4; ++e) o4[e] = rs * (gy[v][e] - s1 - xh[v][e] * s2);
             if (dres) o4 += *reinterpret_cast<const f32x4*>(dres + off);
             *reinterpret_cast<f32x4*>(dx + off) = o4;
+            if (dx16) *reinterpret_cast<ln_bf16x4*>(dx16 + off) = __builtin_convertvector(o4, ln_bf16x4);      // bf16 twin for the GEMMs
         }
     }
     // reduce the RPB row-groups of this block, then write one partial slab
@@ -183,7 +185,8 @@ __global__ __launch_bounds__(256) void ln_fwd_generic_kernel(const float* __rest
 __global__ __launch_bounds__(256) void ln_bwd_generic_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ dres,
-                                                              float* __restrict__ dx, float* __restrict__ partial, int M, int C) {
+                                                              float* __restrict__ dx, float* __restrict__ partial, int M, int C,
+                                                              __bf16* __restrict__ dx16) {
     extern __shared__ float red[];        // [4 waves][2C]
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, nchunk = C >> 2;
     f32x4 dg[GEN_MAXV], db[GEN_MAXV];
@@ -223,6 +226,7 @@ __global__ __launch_bounds__(256) void ln_bwd_generic_kernel(const float* __rest
                 for (int e = 0; e < 4; ++e) o4[e] = rs * (gy[v][e] - s1 - xh[v][e] * s2);
                 if (dres) o4 += *reinterpret_cast<const f32x4*>(dres + row * C + 4 * ch);
                 *reinterpret_cast<f32x4*>(dx + row * C + 4 * ch) = o4;
+                if (dx16) *reinterpret_cast<ln_bf16x4*>(dx16 + row * C + 4 * ch) = __builtin_convertvector(o4, ln_bf16x4);
             }
         }
     }
@@ -251,8 +255,8 @@ void launch_fwd(const float* x, const float* g, const float* b, float* y, float*
 }
 template <int LPR, int VPL>
 void launch_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* g,
-                const float* dres, float* dx, float* partial, int M, hipStream_t st) {
-    hipLaunchKernelGGL((ln_bwd_kernel<LPR, VPL>), dim3(ln_grid(M, 256 / LPR)), dim3(256), 0, st, dy, x, mean, rstd, g, dres, dx, partial, M);
+                const float* dres, float* dx, float* partial, int M, __bf16* dx16, hipStream_t st) {
+    hipLaunchKernelGGL((ln_bwd_kernel<LPR, VPL>), dim3(ln_grid(M, 256 / LPR)), dim3(256), 0, st, dy, x, mean, rstd, g, dres, dx, partial, M, dx16);
 }
 
 bool ln_fast(int C) { return C == 64 || C == 128 || C == 256 || C == 512 || C == 32 || C == 1024; }
@@ -294,7 +298,8 @@ size_t cswin_layernorm_bwd_workspace(int M, int C) {
 // dres may be NULL; dx may alias dres.  dgamma/dbeta are overwritten.
 int cswin_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         const float* dres, float* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes,
-                        int M, int C, cswin_reduce_job* deferred, void* stream) {
+                        int M, int C, cswin_reduce_job* deferred, void* dx_bf16, void* stream) {
+    __bf16* dx16 = (__bf16*)dx_bf16;
     CSWIN_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && M > 0, CSWIN_ERR_SHAPE, "layernorm_bwd: bad arguments");
     CSWIN_REQUIRE(ln_supported(C), CSWIN_ERR_UNSUPPORTED, "layernorm: C=%d must be a multiple of 4, at most 1024", C);
     CSWIN_REQUIRE(workspace && ws_bytes >= cswin_layernorm_bwd_workspace(M, C), CSWIN_ERR_WORKSPACE, "layernorm_bwd: workspace too small");
@@ -303,14 +308,14 @@ int cswin_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
     int lpr = C / 4 > 64 ? 64 : C / 4;
     int nblk = ln_fast(C) ? ln_grid(M, 256 / lpr) : ln_grid(M, 4);
     if (!ln_fast(C))
-        hipLaunchKernelGGL(ln_bwd_generic_kernel, dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), st, dy, x, mean, rstd, gamma, dres, dx, partial, M, C);
+        hipLaunchKernelGGL(ln_bwd_generic_kernel, dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), st, dy, x, mean, rstd, gamma, dres, dx, partial, M, C, dx16);
     else switch (C) {
-        case 32: launch_bwd<8, 1>(dy, x, mean, rstd, gamma, dres, dx, partial, M, st); break;
-        case 64: launch_bwd<16, 1>(dy, x, mean, rstd, gamma, dres, dx, partial, M, st); break;
-        case 128: launch_bwd<32, 1>(dy, x, mean, rstd, gamma, dres, dx, partial, M, st); break;
-        case 256: launch_bwd<64, 1>(dy, x, mean, rstd, gamma, dres, dx, partial, M, st); break;
-        case 512: launch_bwd<64, 2>(dy, x, mean, rstd, gamma, dres, dx, partial, M, st); break;
-        case 1024: launch_bwd<64, 4>(dy, x, mean, rstd, gamma, dres, dx, partial, M, st); break;
+        case 32: launch_bwd<8, 1>(dy, x, mean, rstd, gamma, dres, dx, partial, M, dx16, st); break;
+        case 64: launch_bwd<16, 1>(dy, x, mean, rstd, gamma, dres, dx, partial, M, dx16, st); break;
+        case 128: launch_bwd<32, 1>(dy, x, mean, rstd, gamma, dres, dx, partial, M, dx16, st); break;
+        case 256: launch_bwd<64, 1>(dy, x, mean, rstd, gamma, dres, dx, partial, M, dx16, st); break;
+        case 512: launch_bwd<64, 2>(dy, x, mean, rstd, gamma, dres, dx, partial, M, dx16, st); break;
+        case 1024: launch_bwd<64, 4>(dy, x, mean, rstd, gamma, dres, dx, partial, M, dx16, st); break;
     }
     CSWIN_LAUNCH_CHECK();
     cswin_reduce_job job = {partial, dgamma, dbeta, C, 2LL * C, 2LL * C, nblk, 0};

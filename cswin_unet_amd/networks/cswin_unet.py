@@ -308,6 +308,7 @@ class CSWinTransformer(nn.Module):
     # encoder and bottleneck
     def forward_features(self, x):
         self._predraw_drop_path(x.shape[0], x.device)
+        ops.clear_twins()                      # bf16 gradient twins of a previous backward that nobody consumed
         x = self.stage1_conv_embed(x)
         if self.pos_drop.p > 0 and self.training:
             x = ops.dropout(x, self.pos_drop.p)

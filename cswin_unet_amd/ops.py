@@ -113,7 +113,7 @@ class _LayerNorm(Function):
         nbytes = lib().cswin_layernorm_bwd_workspace(M, C)
         ws = _ws(nbytes, x.device)
         call("cswin_layernorm_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), None, ptr(dx), ptr(dg), ptr(db),
-             ptr(ws), nbytes, M, C, None, stream())
+             ptr(ws), nbytes, M, C, None, None, stream())
         return dx, dg, db, None
 
 
@@ -126,6 +126,26 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 # ------------------------------------------------------------------------------------------------
 def _rows_per_sample(x):
     return x.numel() // (x.shape[0] * x.shape[-1])
+
+
+# bf16 TWINS of fp32 residual-stream gradients (bf16 mode): a block's backward hands the gradient of its input to the next
+# backward as fp32 (the residual path needs it) and leaves a rounded copy here for that block's GEMMs.  An entry is consumed
+# once and only by the very tensor it was made for (same TensorImpl: the entry keeps the tensor alive, so its address cannot be
+# reused); autograd sums fan-outs into new tensors, which then simply have no twin.
+_twins = {}
+
+
+def _twin_put(t, t16):
+    _twins[t.data_ptr()] = (t, t16)
+
+
+def _twin_take(t):
+    e = _twins.pop(t.data_ptr(), None)
+    return e[1] if e is not None and e[0]._cdata == t._cdata else None
+
+
+def clear_twins():
+    _twins.clear()
 
 
 def _wsrc(w):
@@ -483,9 +503,12 @@ class _CSWinBlock(Function):
         jobs = (ReduceJob * 8)()
         J = lambda i: ctypes.cast(ctypes.byref(jobs[i]), ctypes.c_void_p)
         (pq, fq), (pp, fp), (p1, f1), (p2, f2) = [_wsrc(w) if s16 else (ptr(w), 0) for w in (wqkv, wp, w1, w2)]
+        E16 = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=dev)
+        dy16 = _twin_take(dy) if s16 else None          # rounded copy of dy left by the backward that produced it (see _twins)
         # ---- MLP branch ----
         dpre = torch.empty_like(pre)
-        call("cswin_linear_bwd_data", ptr(dy), p2, ptr(dpre), None, 0, ptr(pre), ptr(rs2), L, None, M, C, Hd, precision(), (10 if s16 else 0) | f2, st)
+        call("cswin_linear_bwd_data", ptr(dy16 if dy16 is not None else dy), p2, ptr(dpre), None, 0, ptr(pre), ptr(rs2), L, None, M, C, Hd,
+             precision(), ((10 if s16 else 0) | f2) | (1 if dy16 is not None else 0), st)
         # the four weight gradients are off the critical path: they run as ONE batched launch once all operands exist
         wg = (WgradDesc * 4)()
 
@@ -497,19 +520,24 @@ class _CSWinBlock(Function):
             wg[slot].rows_per_sample, wg[slot].M, wg[slot].N, wg[slot].K, wg[slot].precision = L, M, N_, K_, precision()
 
         dw2, db2 = torch.empty_like(w2), E(C)
-        defer_wgrad(0, dy, act, rs2, dw2, db2, 0, C, Hd, io=2)          # x = act is stored as bf16
+        if dy16 is not None:
+            defer_wgrad(0, dy16, act, rs2, dw2, db2, 0, C, Hd, io=3)   # dy's twin and x = act are stored as bf16
+        else:
+            defer_wgrad(0, dy, act, rs2, dw2, db2, 0, C, Hd, io=2)     # x = act is stored as bf16
         dw1, db1 = torch.empty_like(w1), E(Hd)
         defer_wgrad(1, dpre, h2, None, dw1, db1, 1, Hd, C, io=3)        # dy = dpre and x = h2 are stored as bf16
         dh2 = torch.empty_like(x)                                      # fp32 (x is)
         call("cswin_linear_bwd_data", ptr(dpre), p1, ptr(dh2), None, 0, None, None, 1, None, M, Hd, C, precision(), (1 if s16 else 0) | f1, st)
         dx1, dg2, dbt2 = torch.empty_like(x), E(C), E(C)
+        dx1_16 = E16(B, L, C) if s16 else None                         # the GEMMs below read the twin, the residual path dx1
         call("cswin_layernorm_bwd", ptr(dh2), ptr(x1), ptr(m2), ptr(r2), ptr(g2), ptr(dy), ptr(dx1), ptr(dg2), ptr(dbt2), wsp[2],
-             sizes[2], M, C, J(2), st)
+             sizes[2], M, C, J(2), ptr(dx1_16), st)
         # ---- attention branch ----
         datt = dh2                                                     # reuse
-        call("cswin_linear_bwd_data", ptr(dx1), pp, ptr(datt), None, 0, None, ptr(rs1), L, None, M, C, C, precision(), fp, st)
+        call("cswin_linear_bwd_data", ptr(dx1_16 if s16 else dx1), pp, ptr(datt), None, 0, None, ptr(rs1), L, None, M, C, C, precision(),
+             fp | (1 if s16 else 0), st)
         dwp, dbp = torch.empty_like(wp), E(C)
-        defer_wgrad(2, dx1, att, rs1, dwp, dbp, 3, C, C, io=2)          # x = att is stored as bf16
+        defer_wgrad(2, dx1_16 if s16 else dx1, att, rs1, dwp, dbp, 3, C, C, io=3)      # dx1's twin and x = att are stored as bf16
         early = None
         if _overlap["block"]:
             # fc2, fc1 and proj weight gradients have all their operands now: they run BESIDE the attention backward
@@ -544,8 +572,11 @@ class _CSWinBlock(Function):
         dh1 = datt                                                     # reuse again
         call("cswin_linear_bwd_data", ptr(dqkv), pq, ptr(dh1), None, 0, None, None, 1, None, M, 3 * C, C, precision(), (1 if s16 else 0) | fq, st)
         dx, dg1, dbt1 = torch.empty_like(x), E(C), E(C)
+        dx16 = E16(B, L, C) if s16 else None
         call("cswin_layernorm_bwd", ptr(dh1), ptr(x), ptr(m1), ptr(r1), ptr(g1), ptr(dx1), ptr(dx), ptr(dg1), ptr(dbt1), wsp[5],
-             sizes[5], M, C, J(5), st)
+             sizes[5], M, C, J(5), ptr(dx16), st)
+        if s16:
+            _twin_put(dx, dx16)
         if early is not None:
             torch.cuda.current_stream().wait_stream(_overlap["stream"])      # slabs of the early weight gradients are complete
         call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), 6 + nb, st)

@@ -89,10 +89,12 @@ int cswin_layernorm_fwd(const float* x, const float* gamma, const float* beta, f
  * cswin_wgrad_desc io_bf16 bit 1); mean / rstd stay fp32. */
 size_t cswin_layernorm_bwd_workspace(int M, int C);
 /* dx = dres (optional residual-path gradient, may alias dx) + LN backward; dgamma/dbeta overwritten (by the returned
- * job when `deferred` is given, immediately otherwise) */
+ * job when `deferred` is given, immediately otherwise).  dx_bf16: NULL, or M * C bf16 that receive a rounded copy of dx -- the
+ * bf16 mode's GEMMs read that twin (cswin_linear_bwd_data io_bf16 bit 0, cswin_wgrad_desc io_bf16 bit 0) while the residual
+ * path keeps the fp32 dx. */
 int cswin_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         const float* dres, float* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes,
-                        int M, int C, cswin_reduce_job* deferred, void* stream);
+                        int M, int C, cswin_reduce_job* deferred, void* dx_bf16, void* stream);
 
 /* ---- nn.Linear family: qkv / proj / Mlp.fc1+GELU / fc2 (cswin_unet.py:125,134,17-27), concat_linear{4,3,2}
  *      (:404,417,428 with the torch.cat of :509,518,526 fused as a two-source K loop), 1x1 convs of CARAFE ----

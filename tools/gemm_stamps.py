@@ -13,8 +13,12 @@ cswin_unet_amd.set_matmul_precision(os.environ.get("MATMUL", "fp32"))
 dw = torch.empty(N, K, device="cuda"); db = torch.empty(N, device="cuda")
 nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K); ws = torch.empty(nbytes // 4 + 4, device="cuda")
 h = lib(); h.cswin_debug_set_stamps.argtypes = [ctypes.c_void_p]
+S16 = os.environ.get("STORE16", "0") != "0"        # both operands stored as bf16 (io_bf16 = 5): the LDS-DMA kernel, csrc/gemm16.hip
+x16, w16, dy16 = x.bfloat16(), w.bfloat16(), dy.bfloat16()
 def run():
-    if mode == "fwd": call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, precision(), 0, stream())
+    if S16 and mode == "fwd": call("cswin_linear_fwd", ptr(x16), None, 0, ptr(w16), ptr(b), ptr(y), None, None, None, 1, M, N, K, 1, 5, stream())
+    elif S16 and mode == "dx": call("cswin_linear_bwd_data", ptr(dy16), ptr(w16), ptr(dx), None, 0, None, None, 1, None, M, N, K, 1, 5, stream())
+    elif mode == "fwd": call("cswin_linear_fwd", ptr(x), None, 0, ptr(w), ptr(b), ptr(y), None, None, None, 1, M, N, K, precision(), 0, stream())
     elif mode == "dw": call("cswin_linear_bwd_weight", ptr(dy), ptr(x), None, 0, None, 1, ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, None, precision(), stream())
     else: call("cswin_linear_bwd_data", ptr(dy), ptr(w), ptr(dx), None, 0, None, None, 1, None, M, N, K, precision(), 0, stream())
 for _ in range(3): run()
