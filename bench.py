@@ -227,8 +227,9 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=24)
     ap.add_argument("--matmul", choices=["fp32", "bf16"], default="fp32",
-                    help="fp32: exact fp32 MFMA (BASELINE configs[1], the default and the headline); bf16: Linear/conv operands "
-                         "rounded to bf16 in LDS, bf16 MFMA, fp32 accumulate and storage (configs[2..4])")
+                    help="fp32: exact fp32 MFMA (BASELINE configs[1], the default and the headline); bf16 (configs[2..4]): bf16 MFMA "
+                         "for every Linear / conv, block activations and a weight shadow stored as bf16, fp32 accumulation, "
+                         "residual stream, attention arithmetic, statistics and master weights")
     ap.add_argument("--img-size", type=int, default=None, help="override DATA.IMG_SIZE (384 uses split [1,2,12,12])")
     args = ap.parse_args()
 
@@ -299,7 +300,7 @@ def main():
         out = {"metric": metric, "value": round(world * args.batch * args.steps / elapsed, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.matmul == "fp32" else "bf16 GEMM operands, f32 accumulate/storage", "data": "synthetic",
+               "dtype": "f32" if args.matmul == "fp32" else "bf16 GEMM operands + bf16 block activations / weight shadow, f32 accumulate, residual stream, attention math, master weights", "data": "synthetic",
                "config": {"workload": f"{os.path.splitext(os.path.basename(args.cfg))[0]}, synthetic {config.DATA.IMG_SIZE}x{config.DATA.IMG_SIZE} 9-class, "
                                       f"bs={args.batch}/GPU, {args.matmul} matmul, "
                                       "fwd + 0.4CE+0.6Dice + bwd + SGD(momentum) step, drop_path 0.2",

@@ -129,6 +129,9 @@ def shadow_ptr(w):
 def set_precision(mode):
     prev = _state["precision"]
     _state["precision"] = int(mode)
+    if int(mode) == PREC_BF16 and prev != PREC_BF16:
+        for e in _shadows:                   # the optimiser only maintains the bf16 shadow while the bf16 mode is on
+            e[3]()
     return prev
 
 

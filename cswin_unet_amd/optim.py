@@ -9,7 +9,7 @@ replayed under the poly schedule.
 import numpy as np
 import torch
 
-from ._lib import call, ptr, register_shadow, stream
+from ._lib import call, precision, ptr, register_shadow, stream
 
 _CHUNK = 16384      # floats per gather workgroup
 
@@ -102,7 +102,7 @@ class FlatSGD:
     def apply(self, grad_scale=1.0):
         """p, m <- SGD(flat_grad * grad_scale) (one launch)."""
         call("cswin_sgd_flat", ptr(self.flat_param), ptr(self.flat_grad), ptr(self.flat_mom), self.numel, ptr(self.lr_dev),
-             self.momentum, self.weight_decay, float(grad_scale), ptr(self.flat_param16), stream())
+             self.momentum, self.weight_decay, float(grad_scale), ptr(self.flat_param16) if precision() == 1 else None, stream())
 
     def refresh_shadow(self):
         call("cswin_pack_bf16", ptr(self.flat_param), ptr(self.flat_param16), self.numel, stream())
