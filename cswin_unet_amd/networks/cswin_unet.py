@@ -198,12 +198,32 @@ class CARAFE4(_CarafeBase):
         super().__init__(dim, dim_out, kernel_size, up_factor)
 
 
+class _SumInputChannels(torch.autograd.Function):
+    """w (Cout, Cin, k, k) -> (Cout, 1, k, k); the gradient comes back as a CONTIGUOUS repeat (the flat optimiser packs
+    contiguous gradients; autograd's own backward of sum() would hand it a stride-0 expand)."""
+
+    @staticmethod
+    def forward(ctx, w):
+        ctx.cin = w.shape[1]
+        return w.sum(1, keepdim=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.repeat(1, ctx.cin, 1, 1)
+
+
 class _PatchEmbed(nn.Sequential):
     """Conv2d(in, E, 7, 4, 2) -> 'b c h w -> b (h w) c' -> LayerNorm(E); keys '0.*' and '2.*' as in the reference."""
 
     def forward(self, img):
         conv, norm = self[0], self[2]
-        tok = ops.patch_embed_conv(img, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
+        w = conv.weight
+        if img.shape[1] == 1 and w.shape[1] > 1:
+            # a grey image that the reference repeats to in_chans identical channels (vision_transformer.py:40-41): the
+            # convolution over identical channels is the convolution of the one channel with the kernel summed over its
+            # input channels -- the repeated (B, 3, H, W) tensor is never built
+            w = _SumInputChannels.apply(w)
+        tok = ops.patch_embed_conv(img, w, conv.bias, conv.stride[0], conv.padding[0])
         return ops.layer_norm(tok, norm.weight, norm.bias, norm.eps)
 
 

@@ -1,5 +1,5 @@
 """Model wrapper with the reference's name and call surface (networks/vision_transformer.py:17-72):
-``CSwinUnet(config, img_size, num_classes)(x)``; 1-channel inputs are repeated to 3 channels; ``load_from`` maps an
+``CSwinUnet(config, img_size, num_classes)(x)``; 1-channel inputs behave as if repeated to 3 channels; ``load_from`` maps an
 ImageNet-CSWin checkpoint onto the encoder and mirrors it onto the decoder stages."""
 import logging
 
@@ -27,8 +27,9 @@ class CSwinUnet(nn.Module):
         # the reference also torch.save()s the fresh state_dict into the CWD here (:36); deliberately not replicated
 
     def forward(self, x):
-        grey = x.size(1) == 1
-        return self.cswin_unet(x.repeat(1, 3, 1, 1) if grey else x)
+        # 1-channel inputs: the reference repeats them to 3 channels (:40-41); here the patch embed folds the repeat into its
+        # weights (networks/cswin_unet.py _PatchEmbed), same result up to fp32 summation order
+        return self.cswin_unet(x)
 
     def load_from(self, config):
         """Pretrained encoder weights, also copied onto the decoder (``stageN.*`` -> ``stage_upN.*``); tensors whose shape

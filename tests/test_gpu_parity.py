@@ -313,6 +313,24 @@ def test_block_droppath_injected_mask(N, monkeypatch):
         rel_err(p.grad, P["b." + n].grad, "droppath.grad." + n)
 
 
+def test_patch_embed_grey_input_equals_repeated_channels(N):
+    """A 1-channel image through the stem == the reference's x.repeat(1, 3, 1, 1) through it (vision_transformer.py:40-41): the
+    repeat is folded into the kernel (weights summed over the input channel), output and every gradient agree to fp32
+    summation-order noise."""
+    stem = N._PatchEmbed(torch.nn.Conv2d(3, 64, 7, 4, 2), N.TokenRearrange(), torch.nn.LayerNorm(64)).to(DEV)
+    fill_state_dict(stem, prefix="stem.stage1_conv_embed.")
+    x = T(det_normal("stemgrey.x", (2, 1, 224, 224)))
+    dy = T(det_normal("stemgrey.dy", (2, 56 * 56, 64)))
+    outs = []
+    for inp in (x, x.repeat(1, 3, 1, 1)):
+        stem.zero_grad(set_to_none=True)
+        y = stem(inp)
+        y.backward(dy)
+        outs.append([y.detach().clone()] + [p.grad.clone() for p in stem.parameters()])
+    for n, a, b in zip(["y"] + [n for n, _ in stem.named_parameters()], *outs):
+        assert _rel_l2(a, b) < 1e-5, (n, _rel_l2(a, b))
+
+
 def test_patch_embed_vs_golden(N, golden):
     g = golden("g4_convs")
     stem = N._PatchEmbed(torch.nn.Conv2d(3, 64, 7, 4, 2), N.TokenRearrange(), torch.nn.LayerNorm(64)).to(DEV)
