@@ -137,6 +137,22 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// bf16 matrix instructions of storage mode 7 (bf16 MFMA: BASELINE configs[2..4] pin the softmax / matmul dtype of the attention
+// to bf16, cswin_unet.py:100).  Fragments are built from the SAME fp32 registers / LDS images as the fp32 path and rounded
+// (v_cvt_pk_bf16_f32) on the way in; accumulation, softmax statistics and everything stored stay as before.
+//   mfma32: v_mfma_f32_16x16x32_bf16, a lane holds 8 consecutive k = 8 (lane >> 4) .. + 7  (one instruction = the eight
+//           16x16x4 steps over the 32 head channels);
+//   mfma16: v_mfma_f32_16x16x16_bf16, a lane holds 4 consecutive k = 4 (lane >> 4) .. + 3  (= the four rows 4 kq + r of an
+//           accumulator tile: P / dS tiles are B operands as they stand).
+typedef short attn_s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 attn_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ attn_s16x4 pk4(f32x4 v) { return __builtin_bit_cast(attn_s16x4, __builtin_convertvector(v, attn_bf16x4)); }
+__device__ __forceinline__ attn_bf16x8 pk8(f32x4 lo, f32x4 hi) {
+    return __builtin_shufflevector(__builtin_convertvector(lo, attn_bf16x4), __builtin_convertvector(hi, attn_bf16x4), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ f32x4 mfma16(attn_s16x4 a, attn_s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma32(attn_bf16x8 a, attn_bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
 // ---- LePE taps ------------------------------------------------------------------------------------------------
 // The 3x3 depthwise conv is zero padded at the WINDOW border.  Reads use a clamped address and a select instead of a
 // branch, so that the LDS reads of all taps are in flight together.  THIN: the stripe is one token high or wide
@@ -208,8 +224,8 @@ __device__ __forceinline__ void lepe_wgrad_taps(const AttnBranch& br, const floa
 // three per CU.  The two halves are `units` apart in the grid, i.e. on the same XCD / L2 when units % 8 == 0.
 template <int NT, int QS, int ST>
 __global__ __launch_bounds__(64 * (QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8))) void attn_fwd_kernel(AttnParams p, int units) {
-    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0;      // storage of qkv / dqkv and of y (see AttnParams)
-    (void)Q16; (void)Y16;
+    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0, M16 = (ST & 4) != 0;      // storage of qkv / dqkv and of y, bf16 MFMAs (see AttnParams)
+    (void)Q16; (void)Y16; (void)M16;
     constexpr int NP = 16 * NT;
     constexpr int NW = QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8);
     static_assert(QS == 1 || NT <= 8, "query split only for windows of up to 128 tokens");
@@ -288,6 +304,7 @@ __global__ __launch_bounds__(64 * (QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8))) 
             }
         }
         // S^T tiles: rows = keys (16 kt + 4 kq + reg), col = query li
+        const attn_bf16x8 qb = pk8(f32x4{qr[0], qr[1], qr[2], qr[3]}, f32x4{qr[4], qr[5], qr[6], qr[7]});     // M16 only
         f32x4 s[NT];
         float mx = -INFINITY;
 #pragma unroll
@@ -296,10 +313,14 @@ __global__ __launch_bounds__(64 * (QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8))) 
             const f32x4 k0 = *reinterpret_cast<const f32x4*>(kp);
             const f32x4 k1 = *reinterpret_cast<const f32x4*>(kp + 4);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (M16) {
+                acc = mfma32(pk8(k0, k1), qb, acc);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = mfma4(k0[e], qr[e], acc);
+                for (int e = 0; e < 4; ++e) acc = mfma4(k0[e], qr[e], acc);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = mfma4(k1[e], qr[4 + e], acc);
+                for (int e = 0; e < 4; ++e) acc = mfma4(k1[e], qr[4 + e], acc);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (16 * kt + 4 * kq + r >= N) acc[r] = -INFINITY;
@@ -326,13 +347,21 @@ __global__ __launch_bounds__(64 * (QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8))) 
         // O^T[d][q] = sum_key V[key][d] * P^T[key][q]; the P accumulator tile is the B operand as it stands
         f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
+        for (int kt = 0; kt < NT; ++kt) {
+            if constexpr (M16) {
+                const float* vp = &Vs[(16 * kt + 4 * kq) * LDT + li];
+                const attn_s16x4 pb = pk4(s[kt]);
+                o[0] = mfma16(pk4(f32x4{vp[0], vp[LDT], vp[2 * LDT], vp[3 * LDT]}), pb, o[0]);
+                o[1] = mfma16(pk4(f32x4{vp[16], vp[LDT + 16], vp[2 * LDT + 16], vp[3 * LDT + 16]}), pb, o[1]);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float* vp = &Vs[(16 * kt + 4 * kq + r) * LDT + li];
-                o[0] = mfma4(vp[0], s[kt][r], o[0]);
-                o[1] = mfma4(vp[16], s[kt][r], o[1]);
+                for (int r = 0; r < 4; ++r) {
+                    const float* vp = &Vs[(16 * kt + 4 * kq + r) * LDT + li];
+                    o[0] = mfma4(vp[0], s[kt][r], o[0]);
+                    o[1] = mfma4(vp[16], s[kt][r], o[1]);
+                }
             }
+        }
         // lane now holds O^T[d = 16 df + 4 kq + e][q = li]
         if (qt == qt0) ATTN_STAMP(3);
         if (qvalid) {
@@ -377,8 +406,8 @@ __device__ __forceinline__ float oct_sum(float v) {
 //   P3  K fragments -> LDS over the dead Q image; dQ^T = K^T dS^T per query tile (one per wave) -> global.
 template <int NT, int ST>
 __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {      // 4 waves per SIMD: <= 128 VGPRs, two workgroups per CU at NT = 7
-    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0;      // storage of qkv / dqkv and of y (see AttnParams)
-    (void)Q16; (void)Y16;
+    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0, M16 = (ST & 4) != 0;      // storage of qkv / dqkv and of y, bf16 MFMAs (see AttnParams)
+    (void)Q16; (void)Y16; (void)M16;
     constexpr int NP = 16 * NT;
     constexpr int NTHREADS = 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -571,12 +600,19 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
     f32x4 dVt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x4 dKt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const bool colok = 16 * kw + li < S;               // dS columns beyond the stride would land in the next row
+    const attn_bf16x8 kb = pk8(f32x4{kf[0], kf[1], kf[2], kf[3]}, f32x4{kf[4], kf[5], kf[6], kf[7]});       // M16 only
+    const attn_bf16x8 vb = pk8(f32x4{vf[0], vf[1], vf[2], vf[3]}, f32x4{vf[4], vf[5], vf[6], vf[7]});
     auto s_dp = [&](int qt, f32x4& sa, f32x4& da) {
         const float* qp = &QK[(16 * qt + li) * LDT + 8 * kq];
         const float* dp = &Ds[(16 * qt + li) * LDT + 8 * kq];
         const f32x4 q0 = *reinterpret_cast<const f32x4*>(qp), q1 = *reinterpret_cast<const f32x4*>(qp + 4);
         const f32x4 d0 = *reinterpret_cast<const f32x4*>(dp), d1 = *reinterpret_cast<const f32x4*>(dp + 4);
         sa = da = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (M16) {
+            sa = mfma32(pk8(q0, q1), kb, sa);
+            da = mfma32(pk8(d0, d1), vb, da);
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             sa = mfma4(q0[e], kf[e], sa);               // S[q][key] = sum_d Q[q][d] K[key][d]
@@ -602,16 +638,30 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
             pr[r] = kvalid ? __expf(sa[r] * p.scale - ls[r]) : 0.f;
             ds[r] = pr[r] * (da[r] - de[r]);
         }
+        if constexpr (M16) {
+            const int q0row = 16 * qt + 4 * kq;
+            const float* dop = &Ds[q0row * LDT + li];
+            const float* qp = &QK[q0row * LDT + li];
+            const attn_s16x4 prb = pk4(pr), dsb = pk4(ds);
+            dVt[0] = mfma16(pk4(f32x4{dop[0], dop[LDT], dop[2 * LDT], dop[3 * LDT]}), prb, dVt[0]);
+            dVt[1] = mfma16(pk4(f32x4{dop[16], dop[LDT + 16], dop[2 * LDT + 16], dop[3 * LDT + 16]}), prb, dVt[1]);
+            dKt[0] = mfma16(pk4(f32x4{qp[0], qp[LDT], qp[2 * LDT], qp[3 * LDT]}), dsb, dKt[0]);
+            dKt[1] = mfma16(pk4(f32x4{qp[16], qp[LDT + 16], qp[2 * LDT + 16], qp[3 * LDT + 16]}), dsb, dKt[1]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qrow = 16 * qt + 4 * kq + r;
-            const float* dop = &Ds[qrow * LDT + li];
-            const float* qp = &QK[qrow * LDT + li];
-            dVt[0] = mfma4(dop[0], pr[r], dVt[0]);
-            dVt[1] = mfma4(dop[16], pr[r], dVt[1]);
-            dKt[0] = mfma4(qp[0], ds[r], dKt[0]);
-            dKt[1] = mfma4(qp[16], ds[r], dKt[1]);
-            if (colok) VS[qrow * S + 16 * kw + li] = ds[r];
+            for (int r = 0; r < 4; ++r)
+                if (colok) VS[(q0row + r) * S + 16 * kw + li] = ds[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qrow = 16 * qt + 4 * kq + r;
+                const float* dop = &Ds[qrow * LDT + li];
+                const float* qp = &QK[qrow * LDT + li];
+                dVt[0] = mfma4(dop[0], pr[r], dVt[0]);
+                dVt[1] = mfma4(dop[16], pr[r], dVt[1]);
+                dKt[0] = mfma4(qp[0], ds[r], dKt[0]);
+                dKt[1] = mfma4(qp[16], ds[r], dKt[1]);
+                if (colok) VS[qrow * S + 16 * kw + li] = ds[r];
+            }
         }
         sa = sn;
         da = dn;
@@ -649,11 +699,18 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
         for (int kt = 0; kt < NT; ++kt) {
             // columns beyond the stride read the head of the next row (finite) against K rows that are zero
             const f32x4 ds = *reinterpret_cast<const f32x4*>(&VS[(16 * qt + li) * S + 16 * kt + 4 * kq]);
+            if constexpr (M16) {
+                const float* kp = &QK[(16 * kt + 4 * kq) * LDT + li];
+                const attn_s16x4 dsb = pk4(ds);
+                dQt[0] = mfma16(pk4(f32x4{kp[0], kp[LDT], kp[2 * LDT], kp[3 * LDT]}), dsb, dQt[0]);
+                dQt[1] = mfma16(pk4(f32x4{kp[16], kp[LDT + 16], kp[2 * LDT + 16], kp[3 * LDT + 16]}), dsb, dQt[1]);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float* kp = &QK[(16 * kt + 4 * kq + r) * LDT + li];
-                dQt[0] = mfma4(kp[0], ds[r], dQt[0]);
-                dQt[1] = mfma4(kp[16], ds[r], dQt[1]);
+                for (int r = 0; r < 4; ++r) {
+                    const float* kp = &QK[(16 * kt + 4 * kq + r) * LDT + li];
+                    dQt[0] = mfma4(kp[0], ds[r], dQt[0]);
+                    dQt[1] = mfma4(kp[16], ds[r], dQt[1]);
+                }
             }
         }
         const int tq = 16 * qt + li;
@@ -699,8 +756,8 @@ __device__ __forceinline__ int token_of2(const AttnBranch& br, int ih, int iw, i
 // grid: ceil(B * L * heads_total / 32) blocks of 256 threads; 8 lanes per (token, head)
 template <int ST>
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
-    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0;      // storage of qkv / dqkv and of y (see AttnParams)
-    (void)Q16; (void)Y16;
+    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0, M16 = (ST & 4) != 0;      // storage of qkv / dqkv and of y, bf16 MFMAs (see AttnParams)
+    (void)Q16; (void)Y16; (void)M16;
     const int L = p.reso * p.reso, C3 = 3 * p.C;
     const long item = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
     const int j = threadIdx.x & 7;
@@ -748,8 +805,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
 // one workgroup (4 waves) = 64 keys of one (branch, window, head); wave w owns keys [k0 + 16 w, +16)
 template <int ST>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk) {
-    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0;      // storage of qkv / dqkv and of y (see AttnParams)
-    (void)Q16; (void)Y16;
+    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0, M16 = (ST & 4) != 0;      // storage of qkv / dqkv and of y, bf16 MFMAs (see AttnParams)
+    (void)Q16; (void)Y16; (void)M16;
     __shared__ __attribute__((aligned(16))) float Qc[64 * LDT];
     __shared__ __attribute__((aligned(16))) float Dc[64 * LDT];
     __shared__ __attribute__((aligned(16))) float lse_c[64];
@@ -863,8 +920,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk
 // one workgroup (4 waves) = 64 queries of one (branch, window, head); wave w owns queries [q0 + 16 w, +16)
 template <int ST>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk) {
-    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0;      // storage of qkv / dqkv and of y (see AttnParams)
-    (void)Q16; (void)Y16;
+    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0, M16 = (ST & 4) != 0;      // storage of qkv / dqkv and of y, bf16 MFMAs (see AttnParams)
+    (void)Q16; (void)Y16; (void)M16;
     __shared__ __attribute__((aligned(16))) float Kc[64 * LDT];
     __shared__ __attribute__((aligned(16))) float Vc[64 * LDT];
     const BigWg w = decode_big(p, blockIdx.x, nblk);
@@ -949,8 +1006,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk)
 constexpr int LW_SUB = 4;
 template <int ST>
 __global__ __launch_bounds__(256) void lepe_wgrad_kernel(AttnParams p) {
-    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0;      // storage of qkv / dqkv and of y (see AttnParams)
-    (void)Q16; (void)Y16;
+    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0, M16 = (ST & 4) != 0;      // storage of qkv / dqkv and of y, bf16 MFMAs (see AttnParams)
+    (void)Q16; (void)Y16; (void)M16;
     __shared__ __attribute__((aligned(16))) float red[16 * 8 * 4];
     const int sub = (int)blockIdx.x % LW_SUB;
     const WgInfo w = decode_wg(p, (int)blockIdx.x / LW_SUB);
@@ -1094,7 +1151,8 @@ int launch_fwd_q(const AttnParams& p, int nwg, hipStream_t st) {
 
 template <int NT>
 int launch_fwd(const AttnParams& p, int nwg, hipStream_t st) {
-    return p.qkv_bf16 == 3 ? launch_fwd_q<NT, 3>(p, nwg, st) : p.qkv_bf16 ? launch_fwd_q<NT, 1>(p, nwg, st) : launch_fwd_q<NT, 0>(p, nwg, st);
+    return p.qkv_bf16 == 7 ? launch_fwd_q<NT, 7>(p, nwg, st) : p.qkv_bf16 == 3 ? launch_fwd_q<NT, 3>(p, nwg, st)
+         : p.qkv_bf16 ? launch_fwd_q<NT, 1>(p, nwg, st) : launch_fwd_q<NT, 0>(p, nwg, st);
 }
 
 inline int ds_stride_for(int N) {            // smallest stride >= N with stride = 4 (mod 8): 16-B aligned rows, and the four
@@ -1124,7 +1182,8 @@ int launch_bwd2_q(const AttnParams& p, int nwg, hipStream_t st) {
 
 template <int NT>
 int launch_bwd2(const AttnParams& p, int nwg, hipStream_t st) {
-    return p.qkv_bf16 == 3 ? launch_bwd2_q<NT, 3>(p, nwg, st) : p.qkv_bf16 ? launch_bwd2_q<NT, 1>(p, nwg, st) : launch_bwd2_q<NT, 0>(p, nwg, st);
+    return p.qkv_bf16 == 7 ? launch_bwd2_q<NT, 7>(p, nwg, st) : p.qkv_bf16 == 3 ? launch_bwd2_q<NT, 3>(p, nwg, st)
+         : p.qkv_bf16 ? launch_bwd2_q<NT, 1>(p, nwg, st) : launch_bwd2_q<NT, 0>(p, nwg, st);
 }
 
 template <int Q16>
@@ -1155,7 +1214,8 @@ int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* co
                    int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split, float scale, int qkv_bf16,
                    void* stream) {
     AttnParams p = {};
-    CSWIN_REQUIRE(qkv_bf16 == 0 || qkv_bf16 == 1 || qkv_bf16 == 3, CSWIN_ERR_UNSUPPORTED, "attn: storage mode %d (0 = fp32, 1 = qkv / dqkv bf16, 3 = qkv / dqkv and y bf16)", qkv_bf16);
+    CSWIN_REQUIRE(qkv_bf16 == 0 || qkv_bf16 == 1 || qkv_bf16 == 3 || qkv_bf16 == 7, CSWIN_ERR_UNSUPPORTED,
+                  "attn: mode %d (0 = fp32, 1 = qkv / dqkv stored as bf16, 3 = also y, 7 = also bf16 MFMAs)", qkv_bf16);
     p.qkv_bf16 = qkv_bf16;
     int nt, nwg;
     int rc = fill_params(p, "attn_fwd", B, reso, C, nbranch, heads, idx, split, scale, &nt, &nwg);
@@ -1198,7 +1258,8 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
                    void* workspace, size_t ws_bytes, int B, int reso, int C, int nbranch, const int* heads, const int* idx,
                    int split, float scale, cswin_reduce_job* deferred, int qkv_bf16, void* stream) {
     AttnParams p = {};
-    CSWIN_REQUIRE(qkv_bf16 == 0 || qkv_bf16 == 1 || qkv_bf16 == 3, CSWIN_ERR_UNSUPPORTED, "attn: storage mode %d (0 = fp32, 1 = qkv / dqkv bf16, 3 = qkv / dqkv and y bf16)", qkv_bf16);
+    CSWIN_REQUIRE(qkv_bf16 == 0 || qkv_bf16 == 1 || qkv_bf16 == 3 || qkv_bf16 == 7, CSWIN_ERR_UNSUPPORTED,
+                  "attn: mode %d (0 = fp32, 1 = qkv / dqkv stored as bf16, 3 = also y, 7 = also bf16 MFMAs)", qkv_bf16);
     p.qkv_bf16 = qkv_bf16;
     int nt, nwg;
     int rc = fill_params(p, "attn_bwd", B, reso, C, nbranch, heads, idx, split, scale, &nt, &nwg);
@@ -1223,7 +1284,7 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
         // windows of more than 112 tokens (384x384: N = 144, 288): two-pass path
         const int N = p.br[0].H_sp * p.br[0].W_sp, nblk = (N + 63) / 64;
         const long items = (long)B * p.heads_total * reso * reso;
-        if (p.qkv_bf16 == 3) launch_bwd_two_pass<3>(p, items, nwg, nblk, st);
+        if (p.qkv_bf16 >= 3) launch_bwd_two_pass<3>(p, items, nwg, nblk, st);        // the large-window kernels keep fp32 MFMAs (mode 7 = 3 there)
         else if (p.qkv_bf16) launch_bwd_two_pass<1>(p, items, nwg, nblk, st);
         else launch_bwd_two_pass<0>(p, items, nwg, nblk, st);
         rc = CSWIN_OK;

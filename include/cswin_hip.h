@@ -74,8 +74,12 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
                    int split, float scale, cswin_reduce_job* deferred, int qkv_bf16, void* stream);
 /* qkv_bf16: storage mode of both attention entry points.  0: every tensor fp32.  1: qkv (and dqkv) are STORED as bf16 -- the
  * output format of cswin_linear_fwd(io_bf16 bit 1).  3: additionally y (the forward output, re-read by the backward) is stored
- * as bf16 -- the input format of the proj Linear's io_bf16 bit 0.  dy, lse and the LePE parameters / gradients are fp32; the
- * arithmetic of the attention kernels stays fp32. */
+ * as bf16 -- the input format of the proj Linear's io_bf16 bit 0.  In modes 0 - 3 the arithmetic of the attention kernels is
+ * fp32 throughout (v_mfma_f32_16x16x4_f32).  7: mode 3 with bf16 MATRIX instructions (v_mfma_f32_16x16x32_bf16 for QK^T and
+ * dO V^T, v_mfma_f32_16x16x16_bf16 for P V, dV, dK, dQ): operands (scaled q, k, v, P, dS, dO) are rounded to bf16 on their way
+ * into the matrix pipe -- what the reference's softmax(dtype=attn.dtype) @ v does under a bf16 config (cswin_unet.py:100) --,
+ * accumulators, softmax statistics, LePE and everything stored are as in mode 3.  Windows of more than 112 tokens run their
+ * backward with fp32 matrix instructions in every mode.  dy, lse and the LePE parameters / gradients are fp32. */
 
 /* ---- img2windows / windows2img (cswin_unet.py:184-202): index-only, bit-exact ----
  * img (B, C, H, W) -> out (B*nH*nW, H_sp*W_sp, C);   win (B*nH*nW, H_sp*W_sp, C) -> out (B, H, W, C) */

@@ -1008,6 +1008,44 @@ def test_attention_bf16_y_storage_bit_exact(reso, idx, split, dim, heads):
         call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y16), ptr(lse16), B, reso, C, 1, ha, ia, split, 0.0, 2, stream())
 
 
+@pytest.mark.parametrize("reso,idx,split,dim,heads", [(56, 0, 1, 64, 2), (28, 1, 2, 128, 4), (14, 0, 7, 256, 8), (7, -1, 7, 512, 16)])
+def test_attention_bf16_matrix_instructions_vs_fp32(reso, idx, split, dim, heads):
+    """Mode 7 of cswin_attn_fwd / cswin_attn_bwd (bf16 MFMAs) against mode 3 (same bf16-stored q, k, v, y; fp32 MFMAs).  Mode 7
+    rounds the scaled q, the probabilities, dS and dO to bf16 (relative 2^-9 uniform, sigma 1.1e-3 each) on their way into the
+    matrix pipe; k, v are bf16 already.  An output element is a sum of such products, so the error is a few sigma of the output
+    RMS: bounds 5e-3 (y) and 8e-3 (dqkv) in L2 (measured 1.2 - 1.6e-3 and 1.5 - 2.2e-3); the LePE gradients do not pass through the
+    matrix pipe and must not move."""
+    import ctypes
+    from cswin_unet_amd._lib import call, lib, ptr, stream
+    from cswin_unet_amd.ops import _int_array, _ptr_array
+    B = 2
+    C = dim if idx == -1 else dim // 2
+    nh = heads if idx == -1 else heads // 2
+    L = reso * reso
+    qkv16 = T(det_normal(f"attm.{reso}.{idx}.qkv", (B, L, 3 * C))).bfloat16()
+    lw, lb = T(det_normal(f"attm.{reso}.lw", (C, 9)) * 0.3), T(det_normal(f"attm.{reso}.lb", (C,)) * 0.1)
+    dy = T(det_normal(f"attm.{reso}.{idx}.dy", (B, L, C)))
+    ha, ia = _int_array([nh]), _int_array([idx])
+    E = lambda *sh, dt=torch.float32: torch.empty(*sh, dtype=dt, device=DEV)
+    nbytes = lib().cswin_attn_bwd_workspace(B, reso, C, 1, ha, ia, split)
+    res = {}
+    for mode in (3, 7):
+        y, lse = E(B, L, C, dt=torch.bfloat16), E(B, nh, L)
+        call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y), ptr(lse), B, reso, C, 1, ha, ia, split, 0.0, mode, stream())
+        dq, dw_, db_, ws = E(B, L, 3 * C, dt=torch.bfloat16), E(C, 9), E(C), E(nbytes // 4 + 4)
+        call("cswin_attn_bwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(lse), ptr(y), ptr(dy), ptr(dq), _ptr_array([dw_]),
+             _ptr_array([db_]), ptr(ws), nbytes, B, reso, C, 1, ha, ia, split, 0.0, None, mode, stream())
+        torch.cuda.synchronize()
+        res[mode] = (y.float(), lse, dq.float(), dw_, db_)
+    names, bounds = ("y", "lse", "dqkv", "dlepe_w", "dlepe_b"), (5e-3, 1e-3, 8e-3, 1e-6, 1e-6)
+    for n, a, b, bound in zip(names, res[7], res[3], bounds):
+        e = _rel_l2(a, b)
+        with open(LOG, "a") as f:
+            f.write(f"attn_m16.r{reso}.{n} l2 {e:.3e}\n")
+        assert e < bound, (n, e)
+    assert _rel_l2(res[7][0], res[3][0]) > 1e-5, "mode 7 is bit-identical to mode 3: the bf16 matrix path did not run"
+
+
 @pytest.mark.parametrize("dim,reso,heads,split,last", [(64, 56, 2, 1, False), (256, 14, 8, 7, False), (512, 7, 16, 7, True)])
 def test_block_bf16_activation_storage(N, bf16_matmul, dim, reso, heads, split, last):
     """bf16 mode stores both LayerNorm outputs, qkv, the attention output, the MLP hidden pair and the gradients of qkv and of the
