@@ -837,6 +837,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk
     }
     f32x4 dVt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x4 dKt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const attn_bf16x8 kb = pk8(f32x4{kf[0], kf[1], kf[2], kf[3]}, f32x4{kf[4], kf[5], kf[6], kf[7]});       // M16 only
+    const attn_bf16x8 vb = pk8(f32x4{vf[0], vf[1], vf[2], vf[3]}, f32x4{vf[4], vf[5], vf[6], vf[7]});
     for (int q0 = 0; q0 < N; q0 += 64) {
         for (int idx = tid; idx < 64 * 8; idx += 256) {
             const int row = idx >> 3, c4 = idx & 7, tq = q0 + row;
@@ -863,10 +865,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk
             const float* qp = &Qc[(16 * qt + li) * LDT + 8 * kq];
             const float* dp = &Dc[(16 * qt + li) * LDT + 8 * kq];
             f32x4 sa = {0.f, 0.f, 0.f, 0.f}, da = sa;
+            if constexpr (M16) {
+                sa = mfma32(pk8(*reinterpret_cast<const f32x4*>(qp), *reinterpret_cast<const f32x4*>(qp + 4)), kb, sa);
+                da = mfma32(pk8(*reinterpret_cast<const f32x4*>(dp), *reinterpret_cast<const f32x4*>(dp + 4)), vb, da);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                sa = mfma4(qp[e], kf[e], sa);
-                da = mfma4(dp[e], vf[e], da);
+                for (int e = 0; e < 8; ++e) {
+                    sa = mfma4(qp[e], kf[e], sa);
+                    da = mfma4(dp[e], vf[e], da);
+                }
             }
             const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_c[16 * qt + 4 * kq]);
             const f32x4 de = *reinterpret_cast<const f32x4*>(&del_c[16 * qt + 4 * kq]);
@@ -876,15 +883,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk
                 pv[r] = kvalid ? __expf(sa[r] * p.scale - ls[r]) : 0.f;
                 ds[r] = pv[r] * (da[r] - de[r]);
             }
+            if constexpr (M16) {
+                const float* dop = &Dc[(16 * qt + 4 * kq) * LDT + li];
+                const float* qq = &Qc[(16 * qt + 4 * kq) * LDT + li];
+                const attn_s16x4 pvb = pk4(pv), dsb = pk4(ds);
+                dVt[0] = mfma16(pk4(f32x4{dop[0], dop[LDT], dop[2 * LDT], dop[3 * LDT]}), pvb, dVt[0]);
+                dVt[1] = mfma16(pk4(f32x4{dop[16], dop[LDT + 16], dop[2 * LDT + 16], dop[3 * LDT + 16]}), pvb, dVt[1]);
+                dKt[0] = mfma16(pk4(f32x4{qq[0], qq[LDT], qq[2 * LDT], qq[3 * LDT]}), dsb, dKt[0]);
+                dKt[1] = mfma16(pk4(f32x4{qq[16], qq[LDT + 16], qq[2 * LDT + 16], qq[3 * LDT + 16]}), dsb, dKt[1]);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qrow = 16 * qt + 4 * kq + r;
-                const float* dop = &Dc[qrow * LDT + li];
-                const float* qq = &Qc[qrow * LDT + li];
-                dVt[0] = mfma4(dop[0], pv[r], dVt[0]);
-                dVt[1] = mfma4(dop[16], pv[r], dVt[1]);
-                dKt[0] = mfma4(qq[0], ds[r], dKt[0]);
-                dKt[1] = mfma4(qq[16], ds[r], dKt[1]);
+                for (int r = 0; r < 4; ++r) {
+                    const int qrow = 16 * qt + 4 * kq + r;
+                    const float* dop = &Dc[qrow * LDT + li];
+                    const float* qq = &Qc[qrow * LDT + li];
+                    dVt[0] = mfma4(dop[0], pv[r], dVt[0]);
+                    dVt[1] = mfma4(dop[16], pv[r], dVt[1]);
+                    dKt[0] = mfma4(qq[0], ds[r], dKt[0]);
+                    dKt[1] = mfma4(qq[16], ds[r], dKt[1]);
+                }
             }
         }
         __syncthreads();
@@ -955,6 +972,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk)
         for (int e = 0; e < 4; ++e) { qr[e] = q0[e] * p.scale; qr[4 + e] = q1[e] * p.scale; dor[e] = d0[e]; dor[4 + e] = d1[e]; }
     }
     f32x4 dQt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const attn_bf16x8 qb = pk8(f32x4{qr[0], qr[1], qr[2], qr[3]}, f32x4{qr[4], qr[5], qr[6], qr[7]});       // M16 only
+    const attn_bf16x8 dob = pk8(f32x4{dor[0], dor[1], dor[2], dor[3]}, f32x4{dor[4], dor[5], dor[6], dor[7]});
     for (int k0 = 0; k0 < N; k0 += 64) {
         for (int idx = tid; idx < 64 * 8; idx += 256) {
             const int row = idx >> 3, c4 = idx & 7, tk = k0 + row;
@@ -973,19 +992,35 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk)
             const float* kp = &Kc[(16 * kt + li) * LDT + 8 * kq];
             const float* vp = &Vc[(16 * kt + li) * LDT + 8 * kq];
             f32x4 sa = {0.f, 0.f, 0.f, 0.f}, da = sa;       // S^T / dP^T tiles: rows = keys, col = this lane's query
+            if constexpr (M16) {
+                sa = mfma32(pk8(*reinterpret_cast<const f32x4*>(kp), *reinterpret_cast<const f32x4*>(kp + 4)), qb, sa);
+                da = mfma32(pk8(*reinterpret_cast<const f32x4*>(vp), *reinterpret_cast<const f32x4*>(vp + 4)), dob, da);
+                f32x4 ds4;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                sa = mfma4(kp[e], qr[e], sa);
-                da = mfma4(vp[e], dor[e], da);
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const bool kok = k0 + 16 * kt + 4 * kq + r < N;
+                    const float pv = kok ? __expf(sa[r] - lse_q) : 0.f;
+                    ds4[r] = pv * (da[r] - del_q);
+                }
+                const float* kk = &Kc[(16 * kt + 4 * kq) * LDT + li];
+                const attn_s16x4 dsb = pk4(ds4);
+                dQt[0] = mfma16(pk4(f32x4{kk[0], kk[LDT], kk[2 * LDT], kk[3 * LDT]}), dsb, dQt[0]);
+                dQt[1] = mfma16(pk4(f32x4{kk[16], kk[LDT + 16], kk[2 * LDT + 16], kk[3 * LDT + 16]}), dsb, dQt[1]);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool kok = k0 + 16 * kt + 4 * kq + r < N;
-                const float pv = kok ? __expf(sa[r] - lse_q) : 0.f;
-                const float ds = pv * (da[r] - del_q);
-                const float* kk = &Kc[(16 * kt + 4 * kq + r) * LDT + li];
-                dQt[0] = mfma4(kk[0], ds, dQt[0]);
-                dQt[1] = mfma4(kk[16], ds, dQt[1]);
+                for (int e = 0; e < 8; ++e) {
+                    sa = mfma4(kp[e], qr[e], sa);
+                    da = mfma4(vp[e], dor[e], da);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool kok = k0 + 16 * kt + 4 * kq + r < N;
+                    const float pv = kok ? __expf(sa[r] - lse_q) : 0.f;
+                    const float ds = pv * (da[r] - del_q);
+                    const float* kk = &Kc[(16 * kt + 4 * kq + r) * LDT + li];
+                    dQt[0] = mfma4(kk[0], ds, dQt[0]);
+                    dQt[1] = mfma4(kk[16], ds, dQt[1]);
+                }
             }
         }
         __syncthreads();
@@ -1284,7 +1319,8 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
         // windows of more than 112 tokens (384x384: N = 144, 288): two-pass path
         const int N = p.br[0].H_sp * p.br[0].W_sp, nblk = (N + 63) / 64;
         const long items = (long)B * p.heads_total * reso * reso;
-        if (p.qkv_bf16 >= 3) launch_bwd_two_pass<3>(p, items, nwg, nblk, st);        // the large-window kernels keep fp32 MFMAs (mode 7 = 3 there)
+        if (p.qkv_bf16 == 7) launch_bwd_two_pass<7>(p, items, nwg, nblk, st);
+        else if (p.qkv_bf16 == 3) launch_bwd_two_pass<3>(p, items, nwg, nblk, st);
         else if (p.qkv_bf16) launch_bwd_two_pass<1>(p, items, nwg, nblk, st);
         else launch_bwd_two_pass<0>(p, items, nwg, nblk, st);
         rc = CSWIN_OK;

@@ -78,8 +78,8 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
  * fp32 throughout (v_mfma_f32_16x16x4_f32).  7: mode 3 with bf16 MATRIX instructions (v_mfma_f32_16x16x32_bf16 for QK^T and
  * dO V^T, v_mfma_f32_16x16x16_bf16 for P V, dV, dK, dQ): operands (scaled q, k, v, P, dS, dO) are rounded to bf16 on their way
  * into the matrix pipe -- what the reference's softmax(dtype=attn.dtype) @ v does under a bf16 config (cswin_unet.py:100) --,
- * accumulators, softmax statistics, LePE and everything stored are as in mode 3.  Windows of more than 112 tokens run their
- * backward with fp32 matrix instructions in every mode.  dy, lse and the LePE parameters / gradients are fp32. */
+ * accumulators, softmax statistics, LePE and everything stored are as in mode 3.  dy, lse and the LePE parameters / gradients
+ * are fp32. */
 
 /* ---- img2windows / windows2img (cswin_unet.py:184-202): index-only, bit-exact ----
  * img (B, C, H, W) -> out (B*nH*nW, H_sp*W_sp, C);   win (B*nH*nW, H_sp*W_sp, C) -> out (B, H, W, C) */

@@ -1008,7 +1008,8 @@ def test_attention_bf16_y_storage_bit_exact(reso, idx, split, dim, heads):
         call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y16), ptr(lse16), B, reso, C, 1, ha, ia, split, 0.0, 2, stream())
 
 
-@pytest.mark.parametrize("reso,idx,split,dim,heads", [(56, 0, 1, 64, 2), (28, 1, 2, 128, 4), (14, 0, 7, 256, 8), (7, -1, 7, 512, 16)])
+@pytest.mark.parametrize("reso,idx,split,dim,heads", [(56, 0, 1, 64, 2), (28, 1, 2, 128, 4), (14, 0, 7, 256, 8), (7, -1, 7, 512, 16),
+                                                      (24, 1, 12, 64, 2), (16, -1, 16, 128, 4)])      # the last two: large-window backward
 def test_attention_bf16_matrix_instructions_vs_fp32(reso, idx, split, dim, heads):
     """Mode 7 of cswin_attn_fwd / cswin_attn_bwd (bf16 MFMAs) against mode 3 (same bf16-stored q, k, v, y; fp32 MFMAs).  Mode 7
     rounds the scaled q, the probabilities, dS and dO to bf16 (relative 2^-9 uniform, sigma 1.1e-3 each) on their way into the
