@@ -87,9 +87,9 @@ def attention_roofline(batch, cfg, img_size=224):
         nbytes = lib().cswin_attn_bwd_workspace(batch, reso, C, nb, ha, ia, split[si])
         ws = torch.empty(nbytes // 4 + 4, device=dev)
         t_f = _graph_time(lambda: call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(lse), batch, reso, C, nb, ha, ia,
-                                       split[si], 0.0, 0, stream()))
+                                       split[si], 0.0, 0.0, 0, 0, stream()))
         t_b = _graph_time(lambda: call("cswin_attn_bwd", ptr(qkv), pa(w), pa(b), ptr(lse), ptr(y), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws),
-                                       nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, None, 0, stream()))
+                                       nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, None, 0.0, 0, 0, stream()))
         flops_f = 4.0 * L * n_tok * C * batch
         n_blocks = 2 * depth[si]
         bytes_f, bytes_b = 16.0 * L * C * batch, 28.0 * L * C * batch

@@ -55,6 +55,9 @@ struct AttnParams {
     int B, reso, C, heads_total;
     int hd;                // real head dim (8, 16, 24 or 32); LDS images and MFMA tiles are zero-padded to HD = 32
     float scale;
+    float drop_p, drop_scale;   // attention-probability dropout (cswin_unet.py:101): p (0 = off) and 1 / (1 - p)
+    unsigned drop_thresh;       // keep iff 24 hash bits >= p * 2^24
+    unsigned long long drop_seed;
     int nbranch;
     int ds_stride;         // fused backward: LDS row stride of the dS image (>= N, = 4 mod 8: conflict-free column writes)
     int slab_rows;         // LePE gradient slab rows per window (1 on every current path)
@@ -95,6 +98,26 @@ template <bool Q16> __device__ __forceinline__ void stdq(const AttnParams& p, fl
 struct WgInfo {
     int bi, b, win, g, N, ih, iw;
 };
+
+// nn.Dropout on the attention probabilities (cswin_unet.py:101, attn_drop_rate > 0; no reference config uses it): the keep factor
+// (0 or 1 / (1 - p)) of probability (query tq, key tk) of (batch, head, window) unit `uid` is a counter-based hash of
+// (seed, element index), so the backward kernels regenerate the forward's mask instead of storing an N x N tensor per head.
+//   forward : y = ((P o M) V) + LePE                     (the softmax statistics are those of the undropped P)
+//   backward: dV = (P o M)^T dO,   dS = P o ((dO V^T) o M - delta),   delta = rowsum(dO o (y - LePE)) as without dropout
+__device__ __forceinline__ unsigned long long attn_mix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ long attn_unit_id(const AttnParams& p, const AttnBranch& br, int b, int g, int win) {
+    return ((long)b * p.heads_total + br.head0 + g) * br.nWin + win;
+}
+__device__ __forceinline__ float attn_keep(const AttnParams& p, long uid, int N, int tq, int tk) {
+    const unsigned long long i = ((unsigned long long)uid * (unsigned)N + (unsigned)tq) * (unsigned)N + (unsigned)tk;
+    const unsigned long long r = attn_mix64(attn_mix64(p.drop_seed) ^ i);
+    return (unsigned)(r >> 40) >= p.drop_thresh ? p.drop_scale : 0.f;
+}
 
 __device__ __forceinline__ WgInfo decode_wg(const AttnParams& p, int wg) {
     WgInfo w;
@@ -342,6 +365,13 @@ __global__ __launch_bounds__(64 * (QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8))) 
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
+        if (p.drop_p > 0.f) {                      // attention dropout: P o M goes into P V, the statistics stay those of P
+            const long uid = attn_unit_id(p, br, w.b, w.g, w.win);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[kt][r] *= attn_keep(p, uid, N, tq, 16 * kt + 4 * kq + r);
+        }
         if (qt == qt0) ATTN_STAMP(2);
 
         // O^T[d][q] = sum_key V[key][d] * P^T[key][q]; the P accumulator tile is the B operand as it stands
@@ -638,6 +668,15 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {  
             pr[r] = kvalid ? __expf(sa[r] * p.scale - ls[r]) : 0.f;
             ds[r] = pr[r] * (da[r] - de[r]);
         }
+        if (p.drop_p > 0.f) {                      // dS = P o (dP o M - delta); dV below takes P o M (pr is not used after it)
+            const long uid = attn_unit_id(p, br, w.b, w.g, w.win);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m = attn_keep(p, uid, N, 16 * qt + 4 * kq + r, tk);
+                ds[r] = pr[r] * (da[r] * m - de[r]);
+                pr[r] *= m;
+            }
+        }
         if constexpr (M16) {
             const int q0row = 16 * qt + 4 * kq;
             const float* dop = &Ds[q0row * LDT + li];
@@ -883,6 +922,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk
                 pv[r] = kvalid ? __expf(sa[r] * p.scale - ls[r]) : 0.f;
                 ds[r] = pv[r] * (da[r] - de[r]);
             }
+            if (p.drop_p > 0.f) {
+                const long uid = attn_unit_id(p, br, w.b, w.g, w.win);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m = attn_keep(p, uid, N, q0 + 16 * qt + 4 * kq + r, tk);
+                    ds[r] = pv[r] * (da[r] * m - de[r]);
+                    pv[r] *= m;
+                }
+            }
             if constexpr (M16) {
                 const float* dop = &Dc[(16 * qt + 4 * kq) * LDT + li];
                 const float* qq = &Qc[(16 * qt + 4 * kq) * LDT + li];
@@ -972,6 +1020,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk)
         for (int e = 0; e < 4; ++e) { qr[e] = q0[e] * p.scale; qr[4 + e] = q1[e] * p.scale; dor[e] = d0[e]; dor[4 + e] = d1[e]; }
     }
     f32x4 dQt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const long uid = attn_unit_id(p, br, w.b, w.g, w.win);      // attention dropout only
     const attn_bf16x8 qb = pk8(f32x4{qr[0], qr[1], qr[2], qr[3]}, f32x4{qr[4], qr[5], qr[6], qr[7]});       // M16 only
     const attn_bf16x8 dob = pk8(f32x4{dor[0], dor[1], dor[2], dor[3]}, f32x4{dor[4], dor[5], dor[6], dor[7]});
     for (int k0 = 0; k0 < N; k0 += 64) {
@@ -1000,7 +1049,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk)
                 for (int r = 0; r < 4; ++r) {
                     const bool kok = k0 + 16 * kt + 4 * kq + r < N;
                     const float pv = kok ? __expf(sa[r] - lse_q) : 0.f;
-                    ds4[r] = pv * (da[r] - del_q);
+                    const float m = p.drop_p > 0.f ? attn_keep(p, uid, N, tq, k0 + 16 * kt + 4 * kq + r) : 1.f;
+                    ds4[r] = pv * (da[r] * m - del_q);
                 }
                 const float* kk = &Kc[(16 * kt + 4 * kq) * LDT + li];
                 const attn_s16x4 dsb = pk4(ds4);
@@ -1016,7 +1066,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p, int nblk)
                 for (int r = 0; r < 4; ++r) {
                     const bool kok = k0 + 16 * kt + 4 * kq + r < N;
                     const float pv = kok ? __expf(sa[r] - lse_q) : 0.f;
-                    const float ds = pv * (da[r] - del_q);
+                    const float m = p.drop_p > 0.f ? attn_keep(p, uid, N, tq, k0 + 16 * kt + 4 * kq + r) : 1.f;
+                    const float ds = pv * (da[r] * m - del_q);
                     const float* kk = &Kc[(16 * kt + 4 * kq + r) * LDT + li];
                     dQt[0] = mfma4(kk[0], ds, dQt[0]);
                     dQt[1] = mfma4(kk[16], ds, dQt[1]);
@@ -1246,9 +1297,11 @@ void cswin_debug_set_attn_stamps(void* p) { g_attn_stamps = (long long*)p; }
 // qkv (B, L, 3C) -> y (B, L, C), lse (B, heads_total, L).  nbranch = 2: branch i uses channels
 // [i*C/2, (i+1)*C/2) with stripe mode idx[i]; nbranch = 1: whole C, idx[0] (normally -1).
 int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, float* y, float* lse,
-                   int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split, float scale, int qkv_bf16,
-                   void* stream) {
+                   int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split, float scale, float drop_p,
+                   unsigned long long drop_seed, int qkv_bf16, void* stream) {
     AttnParams p = {};
+    CSWIN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, CSWIN_ERR_UNSUPPORTED, "attn_fwd: dropout probability %g outside [0, 1)", (double)drop_p);
+    p.drop_p = drop_p; p.drop_scale = 1.0f / (1.0f - drop_p); p.drop_thresh = (unsigned)(drop_p * 16777216.0f); p.drop_seed = drop_seed;
     CSWIN_REQUIRE(qkv_bf16 == 0 || qkv_bf16 == 1 || qkv_bf16 == 3 || qkv_bf16 == 7, CSWIN_ERR_UNSUPPORTED,
                   "attn: mode %d (0 = fp32, 1 = qkv / dqkv stored as bf16, 3 = also y, 7 = also bf16 MFMAs)", qkv_bf16);
     p.qkv_bf16 = qkv_bf16;
@@ -1291,8 +1344,11 @@ size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* 
 int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, const float* lse,
                    const float* y, const float* dy, float* dqkv, float* const* dlepe_w, float* const* dlepe_b,
                    void* workspace, size_t ws_bytes, int B, int reso, int C, int nbranch, const int* heads, const int* idx,
-                   int split, float scale, cswin_reduce_job* deferred, int qkv_bf16, void* stream) {
+                   int split, float scale, cswin_reduce_job* deferred, float drop_p, unsigned long long drop_seed, int qkv_bf16,
+                   void* stream) {
     AttnParams p = {};
+    CSWIN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, CSWIN_ERR_UNSUPPORTED, "attn_bwd: dropout probability %g outside [0, 1)", (double)drop_p);
+    p.drop_p = drop_p; p.drop_scale = 1.0f / (1.0f - drop_p); p.drop_thresh = (unsigned)(drop_p * 16777216.0f); p.drop_seed = drop_seed;
     CSWIN_REQUIRE(qkv_bf16 == 0 || qkv_bf16 == 1 || qkv_bf16 == 3 || qkv_bf16 == 7, CSWIN_ERR_UNSUPPORTED,
                   "attn: mode %d (0 = fp32, 1 = qkv / dqkv stored as bf16, 3 = also y, 7 = also bf16 MFMAs)", qkv_bf16);
     p.qkv_bf16 = qkv_bf16;

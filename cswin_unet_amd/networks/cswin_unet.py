@@ -74,13 +74,12 @@ class LePEAttention(nn.Module):
         q, k, v = qkv[0], qkv[1], qkv[2]
         if q.shape[1] != self.resolution * self.resolution:
             raise AssertionError("flatten img_tokens has wrong size")
-        if self.attn_drop.p > 0 and self.training:
-            # the softmax matrix never exists outside the fused kernel's registers; a mask on it is not built (reference
-            # configs and every yaml of the repo use attn_drop_rate 0)
-            raise NotImplementedError("attention-probability dropout (attn_drop_rate > 0) is not implemented in the fused stripe-attention kernel")
+        # attn_drop (cswin_unet.py:57,101): the softmax matrix exists only in the fused kernel's registers, so the kernel applies
+        # the mask itself (counter-based, regenerated in backward)
         packed = torch.cat([q, k, v], dim=-1)
         return ops.stripe_attention(packed, self.resolution, self.split_size, [self.idx], [self.num_heads],
-                                    [self.get_v.weight], [self.get_v.bias], self.scale)
+                                    [self.get_v.weight], [self.get_v.bias], self.scale,
+                                    attn_drop=self.attn_drop.p if self.training else 0.0)
 
 
 class CSWinBlock(nn.Module):
@@ -124,8 +123,7 @@ class CSWinBlock(nn.Module):
         if L != self.patches_resolution ** 2:
             raise AssertionError("flatten img_tokens has wrong size")
         a = self.attns
-        if a[0].attn_drop.p > 0 and self.training:
-            raise NotImplementedError("attention-probability dropout (attn_drop_rate > 0) is not implemented in the fused stripe-attention kernel")
+        ad = a[0].attn_drop.p if self.training else 0.0          # applied inside the attention kernel
         if type(self.norm1) is not nn.LayerNorm or type(self.norm2) is not nn.LayerNorm:
             raise NotImplementedError("the HIP block fuses nn.LayerNorm only")
         rs1, rs2 = self._keep_scales(x)
@@ -135,12 +133,12 @@ class CSWinBlock(nn.Module):
             n1, n2 = self.norm1, self.norm2
             qkv = ops.linear(ops.layer_norm(x, n1.weight, n1.bias, n1.eps), self.qkv.weight, self.qkv.bias)
             att = ops.stripe_attention(qkv, self.patches_resolution, self.split_size, [m.idx for m in a], [m.num_heads for m in a],
-                                       [m.get_v.weight for m in a], [m.get_v.bias for m in a], a[0].scale)
+                                       [m.get_v.weight for m in a], [m.get_v.bias for m in a], a[0].scale, attn_drop=ad)
             x = ops.dropout(ops.linear(att, self.proj.weight, self.proj.bias), self.proj_drop.p, residual=x, row_scale=rs1)
             return self.mlp(ops.layer_norm(x, n2.weight, n2.bias, n2.eps), residual=x, row_scale=rs2)
         return ops.cswin_block(x, self.patches_resolution, self.split_size, [m.idx for m in a], [m.num_heads for m in a],
                                a[0].scale, self.norm1, self.qkv, self.proj, self.norm2, self.mlp.fc1, self.mlp.fc2,
-                               [m.get_v.weight for m in a], [m.get_v.bias for m in a], rs1, rs2)
+                               [m.get_v.weight for m in a], [m.get_v.bias for m in a], rs1, rs2, attn_drop=ad)
 
 
 def img2windows(img, H_sp, W_sp):

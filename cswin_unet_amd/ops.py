@@ -383,7 +383,7 @@ def matmul_nn(a, b):
 # ------------------------------------------------------------------------------------------------
 class _StripeAttention(Function):
     @staticmethod
-    def forward(ctx, qkv, reso, split, idx, heads, scale, *wb):
+    def forward(ctx, qkv, reso, split, idx, heads, scale, drop, *wb):
         # qkv may arrive STORED as bf16 (the bf16 mode's activation storage): the kernel widens on load, dqkv comes back as bf16
         q16 = qkv.dtype == torch.bfloat16 and qkv.is_cuda
         qkv = qkv.contiguous() if q16 else dev_f32(qkv, "attention qkv")
@@ -397,16 +397,16 @@ class _StripeAttention(Function):
         y = torch.empty(B, L, C, dtype=torch.float32, device=qkv.device)
         lse = torch.empty(B, sum(heads), L, dtype=torch.float32, device=qkv.device)
         call("cswin_attn_fwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(y), ptr(lse), B, reso, C, nb,
-             _int_array(heads), _int_array(idx), split, float(scale or 0.0), int(q16), stream())
+             _int_array(heads), _int_array(idx), split, float(scale or 0.0), drop[0], drop[1], int(q16), stream())
         ctx.save_for_backward(qkv, lse, y, *ws_, *bs_)
-        ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0))
+        ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0), drop)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
         qkv, lse, y, *wb_ = ctx.saved_tensors
-        reso, split, idx, heads, scale = ctx.meta
+        reso, split, idx, heads, scale, drop = ctx.meta
         dy = dev_f32(dy)
         nb = len(idx)
         ws_, bs_ = wb_[:nb], wb_[nb:]
@@ -419,13 +419,21 @@ class _StripeAttention(Function):
         nbytes = lib().cswin_attn_bwd_workspace(B, reso, C, nb, ha, ia, split)
         ws = _ws(nbytes, qkv.device)
         call("cswin_attn_bwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(lse), ptr(y), ptr(dy), ptr(dqkv), _ptr_array(dws),
-             _ptr_array(dbs), ptr(ws), nbytes, B, reso, C, nb, ha, ia, split, scale, None, int(qkv.dtype == torch.bfloat16), stream())
-        return (dqkv, None, None, None, None, None) + tuple(d.view(d.shape[0], 1, 3, 3) for d in dws) + tuple(dbs)
+             _ptr_array(dbs), ptr(ws), nbytes, B, reso, C, nb, ha, ia, split, scale, None, drop[0], drop[1], int(qkv.dtype == torch.bfloat16), stream())
+        return (dqkv, None, None, None, None, None, None) + tuple(d.view(d.shape[0], 1, 3, 3) for d in dws) + tuple(dbs)
 
 
-def stripe_attention(qkv, reso, split, idx, heads, lepe_w, lepe_b, scale=None):
-    """qkv (B, L, 3C) -> (B, L, C).  idx/heads/lepe_w/lepe_b: one entry per branch."""
-    return _StripeAttention.apply(qkv, reso, split, tuple(idx), tuple(heads), scale, *lepe_w, *lepe_b)
+def _attn_drop(p):
+    """(p, seed) of one attention-probability dropout draw (nn.Dropout of cswin_unet.py:57,101); the seed comes from the host
+    generator (torch.manual_seed controls it), the backward kernels regenerate the mask from it."""
+    p = float(p)
+    return (p, _draw_seeds(1)[0]) if p > 0 else (0.0, 0)
+
+
+def stripe_attention(qkv, reso, split, idx, heads, lepe_w, lepe_b, scale=None, attn_drop=0.0):
+    """qkv (B, L, 3C) -> (B, L, C).  idx/heads/lepe_w/lepe_b: one entry per branch.  attn_drop: dropout probability on the
+    attention probabilities (training only; the caller passes 0 in eval mode)."""
+    return _StripeAttention.apply(qkv, reso, split, tuple(idx), tuple(heads), scale, _attn_drop(attn_drop), *lepe_w, *lepe_b)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -439,7 +447,7 @@ class _CSWinBlock(Function):
     block become one."""
 
     @staticmethod
-    def forward(ctx, x, reso, split, idx, heads, scale, eps1, eps2, rs1, rs2, g1, b1, wqkv, bqkv, wp, bp, g2, b2, w1, bb1,
+    def forward(ctx, x, reso, split, idx, heads, scale, eps1, eps2, rs1, rs2, drop, g1, b1, wqkv, bqkv, wp, bp, g2, b2, w1, bb1,
                 w2, bb2, *lepe):
         x = dev_f32(x, "block input")
         B, L, C = x.shape
@@ -467,7 +475,7 @@ class _CSWinBlock(Function):
         att, lse = E16(B, L, C), E(B, sum(heads), L)
         ha, ia = _int_array(heads), _int_array(idx)
         call("cswin_attn_fwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(att), ptr(lse), B, reso, C, nb, ha, ia, split,
-             float(scale or 0.0), 7 if s16 else 0, st)
+             float(scale or 0.0), drop[0], drop[1], 7 if s16 else 0, st)
         x1 = torch.empty_like(x)
         call("cswin_linear_fwd", ptr(att), None, 0, pp, ptr(bp), ptr(x1), None, ptr(x), ptr(rs1), L, M, C, C, precision(), io_x | fp, st)
         h2, m2, r2 = E16(B, L, C), E(M), E(M)
@@ -478,14 +486,14 @@ class _CSWinBlock(Function):
         y = torch.empty_like(x)
         call("cswin_linear_fwd", ptr(act), None, 0, p2, ptr(bb2), ptr(y), None, ptr(x1), ptr(rs2), L, M, C, Hd, precision(), io_x | f2, st)
         ctx.save_for_backward(x, m1, r1, h1, qkv, lse, att, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lw, *lb)
-        ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0), bqkv is not None, s16)
+        ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0), bqkv is not None, s16, drop)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
         (x, m1, r1, h1, qkv, lse, att, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lwb) = ctx.saved_tensors
-        reso, split, idx, heads, scale, has_qkv_bias, s16 = ctx.meta
+        reso, split, idx, heads, scale, has_qkv_bias, s16, drop = ctx.meta
         lw, lb = lwb[:len(idx)], lwb[len(idx):]
         dy = dev_f32(dy)
         B, L, C = x.shape
@@ -555,7 +563,7 @@ class _CSWinBlock(Function):
         naw = h.cswin_attn_bwd_workspace(B, reso, C, nb, ha, ia, split)
         aws = _ws(naw, dev)
         call("cswin_attn_bwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(lse), ptr(att), ptr(datt), ptr(dqkv),
-             _ptr_array(dlw), _ptr_array(dlb), ptr(aws), naw, B, reso, C, nb, ha, ia, split, scale, J(6), 7 if s16 else 0, st)
+             _ptr_array(dlw), _ptr_array(dlb), ptr(aws), naw, B, reso, C, nb, ha, ia, split, scale, J(6), drop[0], drop[1], 7 if s16 else 0, st)
         dwqkv = torch.empty_like(wqkv)
         dbqkv = E(3 * C) if has_qkv_bias else None
         defer_wgrad(3, dqkv, h1, None, dwqkv, dbqkv, 4, 3 * C, C, io=3)  # dy = dqkv and x = h1 are stored as bf16
@@ -580,14 +588,15 @@ class _CSWinBlock(Function):
         if early is not None:
             torch.cuda.current_stream().wait_stream(_overlap["stream"])      # slabs of the early weight gradients are complete
         call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), 6 + nb, st)
-        grads = (dx, None, None, None, None, None, None, None, None, None, dg1, dbt1, dwqkv, dbqkv, dwp, dbp, dg2, dbt2, dw1, db1,
+        grads = (dx, None, None, None, None, None, None, None, None, None, None, dg1, dbt1, dwqkv, dbqkv, dwp, dbp, dg2, dbt2, dw1, db1,
                  dw2, db2)
         return grads + tuple(d.view(d.shape[0], 1, 3, 3) for d in dlw) + tuple(dlb)
 
 
-def cswin_block(x, reso, split, idx, heads, scale, norm1, qkv, proj, norm2, fc1, fc2, lepe_w, lepe_b, rs1=None, rs2=None):
-    """Fused CSWinBlock forward/backward.  norm*/qkv/proj/fc*: nn.Modules holding the parameters."""
-    return _CSWinBlock.apply(x, reso, split, tuple(idx), tuple(heads), scale, norm1.eps, norm2.eps, rs1, rs2,
+def cswin_block(x, reso, split, idx, heads, scale, norm1, qkv, proj, norm2, fc1, fc2, lepe_w, lepe_b, rs1=None, rs2=None, attn_drop=0.0):
+    """Fused CSWinBlock forward/backward.  norm*/qkv/proj/fc*: nn.Modules holding the parameters.  attn_drop: dropout probability
+    on the attention probabilities (pass 0 outside training)."""
+    return _CSWinBlock.apply(x, reso, split, tuple(idx), tuple(heads), scale, norm1.eps, norm2.eps, rs1, rs2, _attn_drop(attn_drop),
                              norm1.weight, norm1.bias, qkv.weight, qkv.bias, proj.weight, proj.bias, norm2.weight,
                              norm2.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, *lepe_w, *lepe_b)
 

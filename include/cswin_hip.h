@@ -62,7 +62,10 @@ int cswin_device_ok(void); /* 1 if the current HIP device is gfx950 */
  * lse (B, sum(heads), L): row log-sum-exp saved for backward.  scale <= 0 selects head_dim^-0.5 (:42). */
 int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, float* y, float* lse,
                    int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split, float scale,
-                   int qkv_bf16, void* stream);
+                   float drop_p, unsigned long long drop_seed, int qkv_bf16, void* stream);
+/* drop_p in [0, 1) (0 = off): nn.Dropout on the attention probabilities (cswin_unet.py:101, attn_drop_rate): y = ((P o M) v) + lepe
+ * with M = keep / (1 - drop_p), keep a counter-based hash of (drop_seed, batch, head, window, query, key).  cswin_attn_bwd called
+ * with the same (drop_p, drop_seed) regenerates the mask; the softmax statistics (lse) are those of the undropped P. */
 size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split);
 /* autograd backward of the above: dqkv (B, L, 3C), dlepe_w[i] (Cb, 9), dlepe_b[i] (Cb) are overwritten.
  * y (the forward output) and lepe_b are only read for windows of more than 112 tokens (384x384 inputs), where a
@@ -71,7 +74,8 @@ size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* 
 int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, const float* lse,
                    const float* y, const float* dy, float* dqkv, float* const* dlepe_w, float* const* dlepe_b,
                    void* workspace, size_t ws_bytes, int B, int reso, int C, int nbranch, const int* heads, const int* idx,
-                   int split, float scale, cswin_reduce_job* deferred, int qkv_bf16, void* stream);
+                   int split, float scale, cswin_reduce_job* deferred, float drop_p, unsigned long long drop_seed, int qkv_bf16,
+                   void* stream);
 /* qkv_bf16: storage mode of both attention entry points.  0: every tensor fp32.  1: qkv (and dqkv) are STORED as bf16 -- the
  * output format of cswin_linear_fwd(io_bf16 bit 1).  3: additionally y (the forward output, re-read by the backward) is stored
  * as bf16 -- the input format of the proj Linear's io_bf16 bit 0.  In modes 0 - 3 the arithmetic of the attention kernels is

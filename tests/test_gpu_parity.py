@@ -990,22 +990,22 @@ def test_attention_bf16_y_storage_bit_exact(reso, idx, split, dim, heads):
     ha, ia = _int_array([nh]), _int_array([idx])
     E = lambda *sh, dt=torch.float32: torch.empty(*sh, dtype=dt, device=DEV)
     y32, y16, lse32, lse16 = E(B, L, C), E(B, L, C, dt=torch.bfloat16), E(B, nh, L), E(B, nh, L)
-    call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y32), ptr(lse32), B, reso, C, 1, ha, ia, split, 0.0, 1, stream())
-    call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y16), ptr(lse16), B, reso, C, 1, ha, ia, split, 0.0, 3, stream())
+    call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y32), ptr(lse32), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, 1, stream())
+    call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y16), ptr(lse16), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, 3, stream())
     assert bool((y16.view(torch.int16) == y32.bfloat16().view(torch.int16)).all()) and bool((lse16 == lse32).all())
     nbytes = lib().cswin_attn_bwd_workspace(B, reso, C, 1, ha, ia, split)
     res = []
     for mode, y in ((1, y16.float()), (3, y16)):
         dq, dw_, db_, ws = E(B, L, 3 * C, dt=torch.bfloat16), E(C, 9), E(C), E(nbytes // 4 + 4)
         call("cswin_attn_bwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(lse32), ptr(y), ptr(dy), ptr(dq), _ptr_array([dw_]),
-             _ptr_array([db_]), ptr(ws), nbytes, B, reso, C, 1, ha, ia, split, 0.0, None, mode, stream())
+             _ptr_array([db_]), ptr(ws), nbytes, B, reso, C, 1, ha, ia, split, 0.0, None, 0.0, 0, mode, stream())
         torch.cuda.synchronize()
         res.append((dq, dw_, db_))
     (a, b, c), (d, e, f) = res
     assert bool((a.view(torch.int16) == d.view(torch.int16)).all()) and bool((b == e).all()) and bool((c == f).all())
     from cswin_unet_amd._lib import CswinHipError
     with pytest.raises(CswinHipError):
-        call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y16), ptr(lse16), B, reso, C, 1, ha, ia, split, 0.0, 2, stream())
+        call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y16), ptr(lse16), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, 2, stream())
 
 
 @pytest.mark.parametrize("reso,idx,split,dim,heads", [(56, 0, 1, 64, 2), (28, 1, 2, 128, 4), (14, 0, 7, 256, 8), (7, -1, 7, 512, 16),
@@ -1032,10 +1032,10 @@ def test_attention_bf16_matrix_instructions_vs_fp32(reso, idx, split, dim, heads
     res = {}
     for mode in (3, 7):
         y, lse = E(B, L, C, dt=torch.bfloat16), E(B, nh, L)
-        call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y), ptr(lse), B, reso, C, 1, ha, ia, split, 0.0, mode, stream())
+        call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y), ptr(lse), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, mode, stream())
         dq, dw_, db_, ws = E(B, L, 3 * C, dt=torch.bfloat16), E(C, 9), E(C), E(nbytes // 4 + 4)
         call("cswin_attn_bwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(lse), ptr(y), ptr(dy), ptr(dq), _ptr_array([dw_]),
-             _ptr_array([db_]), ptr(ws), nbytes, B, reso, C, 1, ha, ia, split, 0.0, None, mode, stream())
+             _ptr_array([db_]), ptr(ws), nbytes, B, reso, C, 1, ha, ia, split, 0.0, None, 0.0, 0, mode, stream())
         torch.cuda.synchronize()
         res[mode] = (y.float(), lse, dq.float(), dw_, db_)
     names, bounds = ("y", "lse", "dqkv", "dlepe_w", "dlepe_b"), (5e-3, 1e-3, 8e-3, 1e-6, 1e-6)
@@ -1262,6 +1262,87 @@ def test_block_with_drop_rate_matches_composition(N, ops):
     rel_err(x.grad, xr.grad, "dropblk.dx")
     for n in ("qkv.weight", "proj.weight", "mlp.fc1.weight", "mlp.fc2.bias", "norm2.weight"):
         rel_err(dict(blk.named_parameters())[n].grad, P[n].grad, "dropblk.grad." + n)
+
+
+@pytest.mark.parametrize("reso,idx,split,dim,heads", [(28, 1, 2, 128, 4), (14, 0, 7, 256, 8), (7, -1, 7, 512, 16), (24, 1, 12, 64, 2)])
+def test_attention_probability_dropout(ops, reso, idx, split, dim, heads):
+    """attn_drop_rate > 0 (nn.Dropout on the softmax matrix, cswin_unet.py:57,101): the mask is a counter-based hash inside the
+    kernels, regenerated by the backward (fused kernel; large-window kernels for reso 24).  Parity of the random stream with
+    torch is unpinned, as for every dropout; what is pinned:
+      * statistics: with q = k = 0 (uniform P = 1/N), v = 1 and no LePE, y = (kept keys) / (N (1 - p)): mean 1, variance
+        p / ((1 - p) N) over the queries;
+      * the backward is the derivative of THIS forward (same seed): directional derivative by central differences;
+      * p = 0 is the plain kernel (bit-identical)."""
+    import ctypes
+    from cswin_unet_amd._lib import call, lib, ptr, stream
+    from cswin_unet_amd.ops import _int_array, _ptr_array
+    B, p_drop, seed = 2, 0.25, 1234567
+    C = dim if idx == -1 else dim // 2
+    nh = heads if idx == -1 else heads // 2
+    L = reso * reso
+    Ntok = L if idx == -1 else reso * split
+    ha, ia = _int_array([nh]), _int_array([idx])
+    E = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=DEV)
+    nbytes = lib().cswin_attn_bwd_workspace(B, reso, C, 1, ha, ia, split)
+
+    def fwd(qkv, lw, lb, p, sd):
+        y, lse = E(B, L, C), E(B, nh, L)
+        call("cswin_attn_fwd", ptr(qkv), _ptr_array([lw]), _ptr_array([lb]), ptr(y), ptr(lse), B, reso, C, 1, ha, ia, split, 0.0, p, sd, 0, stream())
+        return y, lse
+
+    # statistics
+    qkv = torch.zeros(B, L, 3 * C, device=DEV)
+    qkv[..., 2 * C:] = 1.0
+    zw, zb = torch.zeros(C, 9, device=DEV), torch.zeros(C, device=DEV)
+    y, _ = fwd(qkv, zw, zb, p_drop, seed)
+    vals = y[..., ::32].double()                 # one channel per head: all channels of a head share the mask
+    n = vals.numel()
+    var = p_drop / ((1 - p_drop) * Ntok)
+    assert abs(float(vals.mean()) - 1.0) < 5 * (var / n) ** 0.5 + 1e-6
+    assert abs(float(vals.var()) / var - 1.0) < 0.15
+    y2, _ = fwd(qkv, zw, zb, p_drop, seed + 1)
+    assert not bool((y2 == y).all()), "another seed drew the same mask"
+    # gradient consistency
+    qkv = T(det_normal(f"adrop.{reso}.qkv", (B, L, 3 * C)) * 0.7)
+    lw, lb = T(det_normal(f"adrop.{reso}.lw", (C, 9)) * 0.3), T(det_normal(f"adrop.{reso}.lb", (C,)) * 0.1)
+    dy, d = T(det_normal(f"adrop.{reso}.dy", (B, L, C))), T(det_normal(f"adrop.{reso}.dir", (B, L, 3 * C)))
+    y, lse = fwd(qkv, lw, lb, p_drop, seed)
+    dq, dw_, db_, ws = E(B, L, 3 * C), E(C, 9), E(C), E(nbytes // 4 + 4)
+    call("cswin_attn_bwd", ptr(qkv), _ptr_array([lw]), _ptr_array([lb]), ptr(lse), ptr(y), ptr(dy), ptr(dq), _ptr_array([dw_]),
+         _ptr_array([db_]), ptr(ws), nbytes, B, reso, C, 1, ha, ia, split, 0.0, None, p_drop, seed, 0, stream())
+    eps = 1e-2
+    yp, _ = fwd(qkv + eps * d, lw, lb, p_drop, seed)
+    ym, _ = fwd(qkv - eps * d, lw, lb, p_drop, seed)
+    num = float(((yp.double() - ym.double()) * dy.double()).sum()) / (2 * eps)
+    ana = float((dq.double() * d.double()).sum())
+    assert abs(num - ana) < 2e-3 * (abs(ana) + float(dq.double().norm() * d.double().norm()) * 1e-2), (num, ana)
+    # p = 0 is the plain kernel
+    y0, _ = fwd(qkv, lw, lb, 0.0, seed)
+    yref = ops.stripe_attention(qkv, reso, split, [idx], [nh], [lw.view(C, 1, 3, 3)], [lb])
+    assert bool((y0 == yref).all())
+
+
+def test_block_attn_drop_runs_and_is_seeded(N):
+    """CSWinBlock(attn_drop > 0).train(): forward / backward run through the fused block op (no NotImplementedError any more),
+    torch.manual_seed reproduces the draw, eval() is deterministic and equals attn_drop = 0."""
+    blk = N.CSWinBlock(128, 28, 4, 2, qkv_bias=True, attn_drop=0.2).to(DEV)
+    fill_state_dict(blk)
+    x = T(det_normal("adropblk.x", (2, 28 * 28, 128)), True)
+    blk.train()
+    torch.manual_seed(5)
+    y1 = blk(x)
+    y1.backward(T(det_normal("adropblk.dy", tuple(y1.shape))))
+    assert x.grad is not None and bool(torch.isfinite(x.grad).all())
+    torch.manual_seed(5)
+    y2 = blk(x)
+    torch.manual_seed(6)
+    y3 = blk(x)
+    assert bool((y1 == y2).all()) and not bool((y1 == y3).all())
+    blk.eval()
+    ref = N.CSWinBlock(128, 28, 4, 2, qkv_bias=True, attn_drop=0.0).to(DEV)
+    fill_state_dict(ref)
+    ref.eval()
+    assert bool((blk(x) == ref(x)).all())
 
 
 def test_dice_loss_probabilities_and_class_weights():
