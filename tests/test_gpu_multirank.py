@@ -26,8 +26,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _rank_main(rank, world, port, backend, wire, use_graph, out):
+def _rank_main(rank, world, port, backend, wire, use_graph, out, matmul="fp32"):
     import torch.distributed as dist
+    import cswin_unet_amd
+    cswin_unet_amd.set_matmul_precision(matmul)
     from cswin_unet_amd.networks import cswin_unet as N
     from cswin_unet_amd.trainer import DataParallelTrainer
     from oracle.determ import det_labels, det_normal, fill_state_dict
@@ -54,14 +56,14 @@ def _rank_main(rank, world, port, backend, wire, use_graph, out):
     dist.destroy_process_group()
 
 
-def _run_two_ranks(wire, use_graph):
+def _run_two_ranks(wire, use_graph, matmul="fp32"):
     import torch.multiprocessing as mp
     n_dev = torch.cuda.device_count()
     backend = "nccl" if n_dev >= 2 else "gloo"
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, backend, wire, use_graph, q), daemon=True) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, backend, wire, use_graph, q, matmul), daemon=True) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
@@ -106,6 +108,19 @@ def test_two_ranks_bf16_gradient_wire(golden):
     losses, _ = res[0]
     assert abs(losses[0] - g["sgd_losses"][0]) < 2e-3 * g["sgd_losses"][0]
     assert np.allclose(losses, g["sgd_losses"], rtol=3e-2), (losses, g["sgd_losses"])
+    assert abs(res[0][1] - res[1][1]) <= 1e-7 * res[0][1]
+
+
+def test_two_ranks_bf16_mode(golden):
+    """BASELINE configs[2] end to end on two ranks: bf16 matmul mode (bf16 activation storage, the optimiser's bf16 weight shadow,
+    attention on bf16 matrix instructions) with the bf16 gradient wire.  Rank 1 starts from different weights, so its shadow is
+    only right if it is re-packed after the broadcast; a stale one would throw the very first global loss off."""
+    g = golden("g5_model")
+    res, _ = _run_two_ranks("bf16", True, matmul="bf16")
+    for r in (0, 1):
+        losses, _ = res[r]
+        assert abs(losses[0] - g["sgd_losses"][0]) < 1e-2 * g["sgd_losses"][0], (r, losses, g["sgd_losses"])
+        assert np.allclose(losses, g["sgd_losses"], rtol=4e-2), (r, losses, g["sgd_losses"])
     assert abs(res[0][1] - res[1][1]) <= 1e-7 * res[0][1]
 
 
