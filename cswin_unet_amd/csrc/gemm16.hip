@@ -53,27 +53,33 @@ __device__ __forceinline__ void g16_dma(const void* gsrc, unsigned lds_dst) {
 template <int N> __device__ __forceinline__ void g16_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void g16_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// S: LDS stages = steps in flight (2 .. 4).  BT: data gradient (W rows run along the reduction index).
-template <int EPI, bool BT, int S, bool PRE16>
-__global__ __launch_bounds__(256) void gemm16_kernel(G16Params p) {
+// S: LDS stages = ring slots in flight (2 .. 4).  BT: data gradient (W rows run along the reduction index).
+// KG: k-groups.  KG = 2 (long reductions with about one workgroup per CU, where a workgroup's life IS the kernel time): eight
+// waves; wave group g takes the 64-k steps 2 i + g, a ring slot holds a PAIR of steps, the two accumulator sets meet in LDS
+// before the epilogue (run by group 0).  The loop is half as long for the same bytes and instructions.
+template <int EPI, bool BT, int S, bool PRE16, int KG>
+__global__ __launch_bounds__(256 * KG) void gemm16_kernel(G16Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char g16_lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3, kgrp = wave8 >> 2;
     const int li = lane & 31, lh = lane >> 5;
+    constexpr int SLOT = KG * G16_STAGE;             // bytes of a ring slot
     // XCD-aware block order (as gemm.hip): each XCD takes a contiguous range of tiles, ordered [m-tile][n-tile]
     const int bid = blockIdx.x, xq = p.nblk >> 3, xr = p.nblk & 7, xcd = bid & 7;
     const int lb = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int m0 = (lb / p.tiles_n) * G16_T, n0 = (lb % p.tiles_n) * G16_T;
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
-    const int nsteps = p.R / G16_T;
+    const int nsteps = p.R / (G16_T * KG);           // loop iterations (KG steps of 64 each)
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)g16_lds;   // LDS byte address of the ring
 
-    // ---- DMA source addresses: wave w moves row groups 2w and 2w + 1 (8 rows each) of both images of a step ----
+    // ---- DMA source addresses.  KG = 1: wave w moves row groups 2w and 2w + 1 (8 rows each) of both images of a step;
+    // KG = 2: wave w (0 .. 7) moves row group w of the four images of a pair of steps.  Four DMAs per wave and iteration.
     const int drow = lane >> 3, slot = lane & 7;
     const unsigned char* a_src[2];
     const unsigned char* b_src[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const int row = (2 * wave + g) * 8 + drow;                       // row of the image
+        const int row = (KG == 2 ? wave8 : 2 * wave + g) * 8 + drow;     // row of the image
         const int ca = slot ^ ((row >> 1) & 7);                          // source chunk of this lane's slot
         const int am = min(m0 + row, p.M - 1);                           // clamped rows are never stored
         a_src[g] = reinterpret_cast<const unsigned char*>(p.A + (long)am * p.lda + 8 * ca);
@@ -86,14 +92,25 @@ __global__ __launch_bounds__(256) void gemm16_kernel(G16Params p) {
             b_src[g] = reinterpret_cast<const unsigned char*>(p.B + (long)row * p.ldb + n0 + 8 * cb);
         }
     }
-    auto issue = [&](int step) {
-        const unsigned st = lds0 + (unsigned)(step % S) * G16_STAGE + (unsigned)wave * 2048;
+    auto issue = [&](int it) {
+        if constexpr (KG == 1) {
+            const unsigned st = lds0 + (unsigned)(it % S) * SLOT + (unsigned)wave * 2048;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) g16_dma(a_src[g] + (long)step * (G16_T * 2), st + g * 1024);
+            for (int g = 0; g < 2; ++g) g16_dma(a_src[g] + (long)it * (G16_T * 2), st + g * 1024);
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const unsigned char* src = BT ? b_src[g] + (long)step * G16_T * p.ldb * 2 : b_src[g] + (long)step * (G16_T * 2);
-            g16_dma(src, st + G16_IMG + g * 1024);
+            for (int g = 0; g < 2; ++g) {
+                const unsigned char* src = BT ? b_src[g] + (long)it * G16_T * p.ldb * 2 : b_src[g] + (long)it * (G16_T * 2);
+                g16_dma(src, st + G16_IMG + g * 1024);
+            }
+        } else {
+            const unsigned st = lds0 + (unsigned)(it % S) * SLOT + (unsigned)wave8 * 1024;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {                                 // g = step of the pair (= the k-group that consumes it)
+                const long step = 2L * it + g;
+                g16_dma(a_src[0] + step * (G16_T * 2), st + g * G16_STAGE);
+                const unsigned char* src = BT ? b_src[0] + step * G16_T * p.ldb * 2 : b_src[0] + step * (G16_T * 2);
+                g16_dma(src, st + g * G16_STAGE + G16_IMG);
+            }
         }
     };
 
@@ -137,7 +154,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(G16Params p) {
         g16_barrier();                     // every wave's part of the step is in LDS; the stage read in step - 1 is free again
         if (step + S - 1 < nsteps) issue(step + S - 1);
         if (stamps && tid == 0 && step == 0) stamps[8L * bid + 1] = __builtin_amdgcn_s_memtime();
-        const unsigned char* aimg = g16_lds + (step % S) * G16_STAGE;
+        const unsigned char* aimg = g16_lds + (step % S) * SLOT + kgrp * G16_STAGE;
         const unsigned char* bimg = aimg + G16_IMG;
 #pragma unroll
         for (int kk = 0; kk < G16_T; kk += 16) {
@@ -169,6 +186,17 @@ __global__ __launch_bounds__(256) void gemm16_kernel(G16Params p) {
     // ---- epilogue (the vector path of gemm_epilogue.h's run_epilogue for one 32 x 32 fragment, operands already in registers):
     // C/D layout (lane = column, registers = rows) -> private [32][36] LDS patch -> lane owns 4 consecutive columns of 4 rows
     acc0 += acc1;
+    if constexpr (KG == 2) {                  // the second k-group's accumulators meet the first's through LDS (lane-contiguous patches)
+        float* xch = reinterpret_cast<float*>(g16_lds) + 4 * EP_WAVE_FLOATS + wave * 16 * 64;
+        if (kgrp == 1) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) xch[g * 64 + lane] = acc0[g];
+        }
+        __syncthreads();
+        if (kgrp == 1) return;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc0[g] += xch[g * 64 + lane];
+    }
     float* wbuf = reinterpret_cast<float*>(g16_lds) + wave * EP_WAVE_FLOATS;
 #pragma unroll
     for (int g = 0; g < 16; ++g) wbuf[((g & 3) + 8 * (g >> 2) + 4 * lh) * EP_LD + li] = acc0[g];
@@ -202,21 +230,32 @@ template <int EPI, bool BT, bool PRE16>
 int g16_launch(const G16Params& p, hipStream_t st) {
     const int nsteps = p.R / G16_T;
     static const int forced = getenv("CSWIN_GEMM16_STAGES") ? atoi(getenv("CSWIN_GEMM16_STAGES")) : 0;      // tuning aid: 2 .. 4
+    static const int forced_kg = getenv("CSWIN_GEMM16_KG") ? atoi(getenv("CSWIN_GEMM16_KG")) : 0;           // tuning aid: 1 / 2
+    // Two k-groups for long reductions with about one workgroup per CU: stand-alone the workgroup life drops (K = 1024: 13.5 k ->
+    // 11.3 k cycles, kernel span 10.0 -> 7.7 us), inside the step it does not pay (7.57 against 7.51 ms/step, twice each):
+    // opt-in only (CSWIN_GEMM16_KG=2 applies it where nsteps >= 8 and nblk <= 400).
+    const bool kg2 = forced_kg == 2 && nsteps >= 8 && nsteps % 2 == 0 && p.nblk <= 400;
     int S = nsteps >= 3 ? 3 : 2;          // 48 KB: three workgroups per CU (measured against 2 and 4 stages: profiles/round2_notes.md)
     if (forced >= 2 && forced <= 4) S = forced;
-    const size_t lds = (size_t)S * G16_STAGE;
-    static_assert(2 * G16_STAGE >= 4 * EP_WAVE_FLOATS * (int)sizeof(float), "the ring must hold the epilogue patches");
-    // dynamic-LDS opt-in of the three instantiations: once per process, thread-safe (a function attribute, not a stream operation)
+    static_assert(2 * G16_STAGE >= 4 * EP_WAVE_FLOATS * (int)sizeof(float), "the smallest ring must hold the epilogue patches");
+    static_assert(4 * G16_STAGE >= (4 * EP_WAVE_FLOATS + 4 * 16 * 64) * (int)sizeof(float), "the two-k-group ring must hold the patches and the exchange");
+    // dynamic-LDS opt-in of the instantiations: once per process, thread-safe (a function attribute, not a stream operation)
     static std::once_flag once;
     static hipError_t status = hipSuccess;
     std::call_once(once, [&] {
-        status = hipFuncSetAttribute((const void*)gemm16_kernel<EPI, BT, 4, PRE16>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G16_STAGE);
-        if (status == hipSuccess) status = hipFuncSetAttribute((const void*)gemm16_kernel<EPI, BT, 3, PRE16>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * G16_STAGE);
+        status = hipFuncSetAttribute((const void*)gemm16_kernel<EPI, BT, 4, PRE16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G16_STAGE);
+        if (status == hipSuccess) status = hipFuncSetAttribute((const void*)gemm16_kernel<EPI, BT, 3, PRE16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * G16_STAGE);
+        if (status == hipSuccess) status = hipFuncSetAttribute((const void*)gemm16_kernel<EPI, BT, 2, PRE16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G16_STAGE);
     });
     if (status != hipSuccess) return 1;
-    if (S == 4) hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 4, PRE16>), dim3(p.nblk), dim3(256), lds, st, p);
-    else if (S == 3) hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 3, PRE16>), dim3(p.nblk), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 2, PRE16>), dim3(p.nblk), dim3(256), lds, st, p);
+    if (kg2) {                             // two ring slots of two steps each: 64 KB, two workgroups per CU
+        hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 2, PRE16, 2>), dim3(p.nblk), dim3(512), 4 * G16_STAGE, st, p);
+        return 0;
+    }
+    const size_t lds = (size_t)S * G16_STAGE;
+    if (S == 4) hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 4, PRE16, 1>), dim3(p.nblk), dim3(256), lds, st, p);
+    else if (S == 3) hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 3, PRE16, 1>), dim3(p.nblk), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 2, PRE16, 1>), dim3(p.nblk), dim3(256), lds, st, p);
     return 0;
 }
 
