@@ -29,7 +29,7 @@ int cswin_ws_gemm(int mode, int epi_mode, const float* A, const float* W, const 
 // both operands stored as bf16 (gemm16.hip); 0 = launched, 1 = not covered
 int cswin_gemm16(int mode, int epi_mode, const void* A, const void* B, const void* epilogue, int M, int NO, int R, void* stream);
 // wgrad16.hip: bf16-operand weight gradients with transposing LDS reads (bf16 matmul mode)
-int cswin_wgrad16_batch(const cswin_wgrad_desc* d, int n, const int* splits, const int* rows_per_split, void* stream);
+int cswin_wgrad16_batch(const cswin_wgrad_desc* d, int n, const int* splits, const int* rows_per_split, void* stream, long long* stamps);
 
 namespace {
 
@@ -893,13 +893,19 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
     static const int w16_off = getenv("CSWIN_WGRAD16") ? atoi(getenv("CSWIN_WGRAD16")) == 0 : 0;     // tuning aid
     if (precision == 1 && (!w16_off || d[0].io_bf16 || (n > 1 && d[1].io_bf16) || (n > 2 && d[2].io_bf16) || (n > 3 && d[3].io_bf16))) {
         // bf16 operands: 128 x 128 tiles, ~3 workgroups per CU over the whole batch (load-bound: see wgrad16.hip)
+        // Workgroups are shared out in proportion to the work (rows x tiles), so that every workgroup of the launch walks the same
+        // number of rows: with equal shares per problem the C x C problem's workgroups finished after 10 k cycles and the C x 4C
+        // ones after 37 k (in-kernel stamps, tools/wgrad16_stamps.py), and the launch lasts as long as its slowest workgroup.
         int splits[WGRAD_BATCH], rps[WGRAD_BATCH];
+        double work_total = 0.0;
+        for (int i = 0; i < n; ++i) work_total += (double)d[i].M * cdiv(d[i].N, 128) * cdiv(d[i].K, 128);
         for (int i = 0; i < n; ++i) {
             const int M = d[i].M, N = d[i].N, K = d[i].K;
             const long slab = ((long)N * K + N) * (long)sizeof(float);
             const int tiles = cdiv(N, 128) * cdiv(K, 128);
             static const int w16_wgs = getenv("CSWIN_W16_WGS") ? atoi(getenv("CSWIN_W16_WGS")) : 768;      // tuning aid
-            int s = (w16_wgs / n) / tiles;
+            static const int w16_even = getenv("CSWIN_W16_EVEN") ? atoi(getenv("CSWIN_W16_EVEN")) : 0;      // tuning aid: 1 = equal share per problem
+            int s = w16_even ? (w16_wgs / n) / tiles : (int)(w16_wgs * ((double)M * tiles / work_total) / tiles + 0.5);
             const int cap = (int)(d[i].ws_bytes / slab);
             if (s > cap) s = cap;
             if (s > M / 64) s = M / 64;
@@ -909,7 +915,7 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
             const long nk = (long)N * K;
             deferred[i] = cswin_reduce_job{(const float*)d[i].workspace, d[i].dw, d[i].dbias, nk, nk + (d[i].dbias ? N : 0), nk + N, splits[i], 0};
         }
-        cswin_wgrad16_batch(d, n, splits, rps, stream);
+        cswin_wgrad16_batch(d, n, splits, rps, stream, g_stamps);
         CSWIN_LAUNCH_CHECK();
         return CSWIN_OK;
     }
@@ -921,7 +927,19 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
         // 1024 workgroups per launch, i.e. exactly 4 per CU, shared by the problems (measured with four problems: 192 / 256 /
         // 320 per problem -> 13.80 / 13.55 / 14.09 ms per step); a quarter of the slab traffic of four stand-alone launches
         static const int batch_env = getenv("CSWIN_GEMM_BATCH_WGS") ? atoi(getenv("CSWIN_GEMM_BATCH_WGS")) : 0;   // tuning aid
-        const int batch_target = batch_env > 0 ? (batch_env < 1024 ? batch_env : 1024) : 1024 / n;   // the workspace query covers <= 1024
+        // Equal shares per problem (the C x C problem then has 294-row workgroups beside the 1176-row ones of the C x 4C problems).
+        // Shares in proportion to the work (CSWIN_GEMM_BATCH_EVEN=0), which pays for the load-bound bf16 kernel above, measured
+        // SLOWER here: 13.70 against 13.28 ms/step -- this kernel is matrix-pipe bound and the extra slabs cost more than the tail.
+        static const int batch_even = getenv("CSWIN_GEMM_BATCH_EVEN") ? atoi(getenv("CSWIN_GEMM_BATCH_EVEN")) : 1;  // tuning aid
+        const int total_wgs = batch_env > 0 ? (batch_env < 1024 ? batch_env : 1024) * n : 1024;
+        int batch_target = total_wgs / n;                                                            // the workspace query covers <= 1024
+        if (!batch_even) {
+            double work = 0.0;
+            for (int j = 0; j < n; ++j) work += (double)d[j].M * cdiv(d[j].N, 64) * cdiv(d[j].K, 64);
+            batch_target = (int)(total_wgs * ((double)M * cdiv(N, 64) * cdiv(K, 64) / work) + 0.5);
+            if (batch_target > 1024) batch_target = 1024;
+            if (batch_target < 1) batch_target = 1;
+        }
         choose_split(M, N, K, &splits, &rps, batch_target);
         CSWIN_REQUIRE((size_t)splits * ((size_t)N * K + N) * sizeof(float) <= d[i].ws_bytes, CSWIN_ERR_WORKSPACE,
                       "linear_bwd_weight_batch: %d slabs do not fit problem %d's workspace", splits, i);

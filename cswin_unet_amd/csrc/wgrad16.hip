@@ -39,6 +39,7 @@ struct W16Batch {
     W16Problem p[W16_MAXP];
     int first[W16_MAXP + 1];
     int n;
+    long long* stamps;              // debug (cswin_debug_set_stamps): [workgroup][8] s_memtime / realtime stamps of thread 0, or NULL
 };
 
 // byte offset of 16-B chunk `ch` (8 bf16) of row `row` inside a [rows][128] bf16 image
@@ -49,7 +50,7 @@ constexpr int W16_LDS = 2 * 2 * W16_MS * 256 + 8 * W16_T * 4;      // 2 stages x
 // One problem's tile.  DY16 / X16: that operand is STORED as bf16 -- compile-time copies of the body (chosen per workgroup in
 // the kernel below): a run-time choice between 8-B and 16-B loads inside fetch() makes the prefetch loads wait for one another.
 template <bool DY16, bool X16>
-__device__ __forceinline__ void wgrad16_tile(const W16Problem& P, const int lb, unsigned char* lds) {
+__device__ __forceinline__ void wgrad16_tile(const W16Problem& P, const int lb, unsigned char* lds, long long* st) {
     const int tiles = P.tiles_n * P.tiles_k;
     const int split = lb / tiles, tile = lb - split * tiles;
     const int nb = (tile / P.tiles_k) * W16_T, kb = (tile % P.tiles_k) * W16_T;
@@ -144,6 +145,7 @@ __device__ __forceinline__ void wgrad16_tile(const W16Problem& P, const int lb, 
         fetch(m_begin);
         stash(0);
         __syncthreads();
+        if (st && threadIdx.x == 0) st[1] = __builtin_amdgcn_s_memtime();
         int stage = 0;
         for (int m0 = m_begin; m0 < m_end; m0 += W16_MS) {
             const bool more = m0 + W16_MS < m_end;
@@ -168,6 +170,7 @@ __device__ __forceinline__ void wgrad16_tile(const W16Problem& P, const int lb, 
         }
     }
 
+    if (st && threadIdx.x == 0) st[2] = __builtin_amdgcn_s_memtime();
     // ---- partial tile -> slab (C/D layout: lane = column k, registers = rows n) ----
     float* slab = P.slab + (long)split * P.slab_stride;
 #pragma unroll
@@ -201,20 +204,23 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(W16Batch b) {
     while (pi + 1 < b.n && (int)blockIdx.x >= b.first[pi + 1]) ++pi;
     const W16Problem& P = b.p[pi];
     const int lb = (int)blockIdx.x - b.first[pi];
+    long long* st = b.stamps ? b.stamps + 8L * blockIdx.x : nullptr;
+    if (st && threadIdx.x == 0) { st[0] = __builtin_amdgcn_s_memtime(); st[4] = __builtin_amdgcn_s_getreg(6164); st[5] = __builtin_amdgcn_s_memrealtime(); }
     if (P.dy_bf16) {
-        if (P.x_bf16) wgrad16_tile<true, true>(P, lb, lds);
-        else wgrad16_tile<true, false>(P, lb, lds);
+        if (P.x_bf16) wgrad16_tile<true, true>(P, lb, lds, st);
+        else wgrad16_tile<true, false>(P, lb, lds, st);
     } else {
-        if (P.x_bf16) wgrad16_tile<false, true>(P, lb, lds);
-        else wgrad16_tile<false, false>(P, lb, lds);
+        if (P.x_bf16) wgrad16_tile<false, true>(P, lb, lds, st);
+        else wgrad16_tile<false, false>(P, lb, lds, st);
     }
+    if (st && threadIdx.x == 0) { st[3] = __builtin_amdgcn_s_memtime(); st[6] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 }  // namespace
 
 // Internal entry used by gemm.hip's cswin_linear_bwd_weight_batch in bf16 matmul mode.  Problems must be 16-B aligned with
 // N % 4 == K % 4 == 0 (the caller checks).  splits[i] <= what problem i's workspace holds.  Returns 0.
-int cswin_wgrad16_batch(const cswin_wgrad_desc* d, int n, const int* splits, const int* rows_per_split, void* stream) {
+int cswin_wgrad16_batch(const cswin_wgrad_desc* d, int n, const int* splits, const int* rows_per_split, void* stream, long long* stamps) {
     W16Batch b = {};
     int blocks = 0;
     for (int i = 0; i < n; ++i) {
@@ -234,6 +240,7 @@ int cswin_wgrad16_batch(const cswin_wgrad_desc* d, int n, const int* splits, con
     }
     b.first[n] = blocks;
     b.n = n;
+    b.stamps = stamps;
     hipLaunchKernelGGL(wgrad16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
     return 0;
 }
