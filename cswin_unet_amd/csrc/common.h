@@ -9,6 +9,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // raw bf16 pairs travel as INTEGER vectors: hipcc 7.2 (gfx950, -O3) miscompiles __builtin_bit_cast of the elements of a 2-float
 // vector (element 1 reads element 0; tools/micro/f32x2_bitcast_probe.hip shows it in the ISA), so there is no f32x2 typedef here
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CSWIN_OK 0

@@ -33,6 +33,7 @@ struct W16Problem {
     float* slab;                    // [splits][N*K + N]
     int M, N, K, rows_per_sample, rows_per_split, tiles_n, tiles_k, has_bias;
     int dy_bf16, x_bf16;            // the operand is stored as bf16 (bf16 activation storage)
+    int dma;                        // both stored as bf16, M % 32 == 0, N % 8 == K % 8 == 0: LDS-DMA tile (below)
     long slab_stride;
 };
 struct W16Batch {
@@ -45,7 +46,12 @@ struct W16Batch {
 // byte offset of 16-B chunk `ch` (8 bf16) of row `row` inside a [rows][128] bf16 image
 __device__ __forceinline__ int img_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
-constexpr int W16_LDS = 2 * 2 * W16_MS * 256 + 8 * W16_T * 4;      // 2 stages x (dy | x) images + bias sums
+constexpr int W16_DMA_S = 3;                                        // LDS-DMA tile: steps in flight
+constexpr int W16_STEP = 2 * W16_MS * 256;                          // bytes of one step's (dy | x) images
+constexpr int W16_SC_SAMPLES = 64;                                  // DropPath factors of the samples a workgroup's rows touch
+constexpr int W16_SC_BYTES = (W16_SC_SAMPLES + W16_DMA_S * W16_MS) * 4;
+constexpr int W16_LDS = W16_DMA_S * W16_STEP + W16_SC_BYTES;        // 48.6 KB (register path: 2 stages + bias sums = 36 KB): 3 workgroups per CU
+static_assert(W16_LDS >= 2 * W16_STEP + 8 * W16_T * 4, "the register path's stages and bias sums must fit");
 
 // One problem's tile.  DY16 / X16: that operand is STORED as bf16 -- compile-time copies of the body (chosen per workgroup in
 // the kernel below): a run-time choice between 8-B and 16-B loads inside fetch() makes the prefetch loads wait for one another.
@@ -198,7 +204,165 @@ __device__ __forceinline__ void wgrad16_tile(const W16Problem& P, const int lb, 
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad16_kernel(W16Batch b) {
+// ---- LDS-DMA tile: both operands stored as bf16 and used as they are (no row scale) ----------------------------------------
+// The register path above spends ~3 k cycles per 32-row step on 256 cycles of MFMA work (tools/wgrad16_stamps.py): one
+// global-load round trip per step, its prefetch reaching one step ahead, and a second register set costs a workgroup per CU.
+// Here the [m][128] images are written by global_load_lds_dwordx4 (no registers: three steps in flight at the same occupancy),
+// the XOR swizzle of img_off applied to the SOURCE chunk, one counted s_waitcnt vmcnt + s_barrier per step.  The bias gradient
+// (column sums of dy) is one more MFMA per fragment against a constant ones operand instead of a pass over the tile.
+// SCALE (DropPath row factors on dy): the factors of the samples this workgroup's rows touch are read once, a 32-entry per-row
+// table is refreshed per step in LDS, and the dy fragments are scaled as they leave LDS (widen, multiply, round: the same
+// arithmetic, element by element, as the register path's scale-then-round).
+__device__ __forceinline__ void w16_dma(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void w16_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void w16_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool SCALE>
+__device__ __forceinline__ void wgrad16_dma_tile(const W16Problem& P, const int lb, unsigned char* lds, long long* st) {
+    const int tiles = P.tiles_n * P.tiles_k;
+    const int split = lb / tiles, tile = lb - split * tiles;
+    const int nb = (tile / P.tiles_k) * W16_T, kb = (tile % P.tiles_k) * W16_T;
+    const int m_begin = split * P.rows_per_split;
+    const int m_end = min(P.M, m_begin + P.rows_per_split);
+    const int nsteps = (m_end - m_begin) / W16_MS;              // whole steps: M and the split size are multiples of 32
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;                    // wave tile: n in [64 wi, +64), k in [64 wj, +64)
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+
+    // DMA: a wave instruction moves 4 image rows (1 KB); wave w moves row groups 2 w, 2 w + 1 of both images of a step
+    const int drow = lane >> 4, slot = lane & 15;
+    const unsigned char* dy_src[2];
+    const unsigned char* x_src[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int row = (2 * wave + g) * 4 + drow;
+        const int ch = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));                    // source chunk of this lane's slot (img_off)
+        const int cn = min(ch, (P.N - nb) / 8 - 1), ck = min(ch, (P.K - kb) / 8 - 1);   // columns beyond N / K: in-range data, never stored
+        dy_src[g] = reinterpret_cast<const unsigned char*>(reinterpret_cast<const __bf16*>(P.dy) + (long)(m_begin + row) * P.N + nb + 8 * cn);
+        x_src[g] = reinterpret_cast<const unsigned char*>(reinterpret_cast<const __bf16*>(P.x) + (long)(m_begin + row) * P.K + kb + 8 * ck);
+    }
+    auto issue = [&](int step) {
+        const unsigned stg = lds0 + (unsigned)(step % W16_DMA_S) * W16_STEP + (unsigned)wave * 2048;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) w16_dma(dy_src[g] + (long)step * W16_MS * P.N * 2, stg + g * 1024);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) w16_dma(x_src[g] + (long)step * W16_MS * P.K * 2, stg + W16_MS * 256 + g * 1024);
+    };
+
+    const int q = (lane & 15) >> 2, pp = lane & 3;
+    auto tr_frag = [&](const unsigned char* img, int cb, int r16) -> bf16x8v {
+        const int col = cb + 16 * ((lane >> 4) & 1) + 4 * pp;
+        const int row = r16 + 8 * lh + q;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + img_off(row, col >> 3) + 2 * (col & 7)));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + img_off(row + 4, col >> 3) + 2 * (col & 7)));
+        const s16x8 f = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        return __builtin_bit_cast(bf16x8v, f);
+    };
+
+    f32x16 acc[2][2], accb[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accb[a][e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
+    }
+    const bool do_bias = P.has_bias && kb == 0 && wj == 0;      // wave-uniform
+    // DropPath factors: samples b0 .. of this workgroup's rows (read BEFORE the first DMA: older in the vmcnt queue)
+    float* sc_tab = reinterpret_cast<float*>(lds + W16_DMA_S * W16_STEP);
+    float* sc_row = sc_tab + W16_SC_SAMPLES;                     // [stage][32]
+    const int b0 = SCALE ? m_begin / P.rows_per_sample : 0;
+    if constexpr (SCALE) {
+        const int nb_s = (m_end - 1) / P.rows_per_sample - b0 + 1;
+        if (tid < nb_s) sc_tab[tid] = P.row_scale[b0 + tid];
+        __syncthreads();
+    }
+    auto fill_rows = [&](int step) {                            // per-row factors of a step (LDS only)
+        if (tid < W16_MS) sc_row[(step % W16_DMA_S) * W16_MS + tid] = sc_tab[(m_begin + step * W16_MS + tid) / P.rows_per_sample - b0];
+    };
+    const s16x8 ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};      // bf16 1.0
+    const bf16x8v ones = __builtin_bit_cast(bf16x8v, ones_s);
+
+    for (int s = 0; s < W16_DMA_S - 1 && s < nsteps; ++s) {
+        issue(s);
+        if constexpr (SCALE) fill_rows(s);
+    }
+    for (int step = 0; step < nsteps; ++step) {
+        const int later = min(W16_DMA_S - 2, nsteps - 1 - step);
+        if (later >= 1) w16_wait<4>();
+        else w16_wait<0>();
+        w16_barrier();                      // the step is in LDS for every wave; the stage read one step ago is free again
+        if (step + W16_DMA_S - 1 < nsteps) {
+            issue(step + W16_DMA_S - 1);
+            if constexpr (SCALE) fill_rows(step + W16_DMA_S - 1);
+        }
+        if (st && threadIdx.x == 0 && step == 0) st[1] = __builtin_amdgcn_s_memtime();
+        const unsigned char* dimg = lds + (step % W16_DMA_S) * W16_STEP;
+        const unsigned char* ximg = dimg + W16_MS * 256;
+#pragma unroll
+        for (int r16 = 0; r16 < W16_MS; r16 += 16) {
+            bf16x8v af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = tr_frag(dimg, 64 * wi + 32 * a, r16);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) bf[c] = tr_frag(ximg, 64 * wj + 32 * c, r16);
+            if constexpr (SCALE) {
+                // a lane's 8 values are rows r16 + 8 lh + 0 .. 7 of its column
+                const float* sr = &sc_row[(step % W16_DMA_S) * W16_MS + r16 + 8 * lh];
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sr), s1 = *reinterpret_cast<const f32x4*>(sr + 4);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const u32x4 raw = __builtin_bit_cast(u32x4, af[a]);
+                    f32x4 lo = {__builtin_bit_cast(float, raw[0] << 16), __builtin_bit_cast(float, raw[0] & 0xffff0000u),
+                                __builtin_bit_cast(float, raw[1] << 16), __builtin_bit_cast(float, raw[1] & 0xffff0000u)};
+                    f32x4 hi = {__builtin_bit_cast(float, raw[2] << 16), __builtin_bit_cast(float, raw[2] & 0xffff0000u),
+                                __builtin_bit_cast(float, raw[3] << 16), __builtin_bit_cast(float, raw[3] & 0xffff0000u)};
+                    af[a] = __builtin_shufflevector(__builtin_convertvector(lo * s0, bf16x4v), __builtin_convertvector(hi * s1, bf16x4v), 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[c], acc[a][c], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) accb[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], ones, accb[a], 0, 0, 0);
+            }
+        }
+    }
+    if (st && threadIdx.x == 0) st[2] = __builtin_amdgcn_s_memtime();
+    float* slab = P.slab + (long)split * P.slab_stride;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int k = kb + 64 * wj + 32 * c + li;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int n = nb + 64 * wi + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                if (n < P.N && k < P.K) slab[(long)n * P.K + k] = acc[a][c][g];
+            }
+        }
+    if (do_bias && li == 0) {               // every column of the ones product holds the row sums: take column 0
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int n = nb + 64 * wi + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                if (n < P.N) slab[(long)P.N * P.K + n] = accb[a][g];
+            }
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void wgrad16_kernel(W16Batch b) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[W16_LDS];
     int pi = 0;
     while (pi + 1 < b.n && (int)blockIdx.x >= b.first[pi + 1]) ++pi;
@@ -206,7 +370,10 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(W16Batch b) {
     const int lb = (int)blockIdx.x - b.first[pi];
     long long* st = b.stamps ? b.stamps + 8L * blockIdx.x : nullptr;
     if (st && threadIdx.x == 0) { st[0] = __builtin_amdgcn_s_memtime(); st[4] = __builtin_amdgcn_s_getreg(6164); st[5] = __builtin_amdgcn_s_memrealtime(); }
-    if (P.dy_bf16) {
+    if (P.dma) {
+        if (P.row_scale) wgrad16_dma_tile<true>(P, lb, lds, st);
+        else wgrad16_dma_tile<false>(P, lb, lds, st);
+    } else if (P.dy_bf16) {
         if (P.x_bf16) wgrad16_tile<true, true>(P, lb, lds, st);
         else wgrad16_tile<true, false>(P, lb, lds, st);
     } else {
@@ -235,6 +402,10 @@ int cswin_wgrad16_batch(const cswin_wgrad_desc* d, int n, const int* splits, con
         P.dy_bf16 = d[i].io_bf16 & 1;
         P.x_bf16 = (d[i].io_bf16 >> 1) & 1;
         P.slab_stride = (long)P.N * P.K + P.N;
+        static const bool dma_off = getenv("CSWIN_W16_DMA") && atoi(getenv("CSWIN_W16_DMA")) == 0;         // tuning aid
+        P.dma = !dma_off && P.dy_bf16 && P.x_bf16 && P.M % W16_MS == 0 && P.rows_per_split % W16_MS == 0 &&
+                P.N % 8 == 0 && P.K % 8 == 0 && ((((uintptr_t)P.dy) | ((uintptr_t)P.x)) & 15) == 0 &&
+                (!P.row_scale || P.rows_per_split / P.rows_per_sample + 2 <= W16_SC_SAMPLES);
         b.first[i] = blocks;
         blocks += P.tiles_n * P.tiles_k * splits[i];
     }

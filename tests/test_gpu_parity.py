@@ -887,7 +887,11 @@ def test_linear_bf16_storage_flags_bit_exact(M, Nn, K):
         dw0, db0 = wgrad(0, with_rs)
         for io in (1, 2, 3):
             dw, db = wgrad(io, with_rs)
-            assert eq(dw, dw0) and eq(db, db0), ("wgrad", io, with_rs)
+            # io = 3 without a row scale runs the LDS-DMA tile, which forms the bias gradient with one more MFMA per fragment
+            # (dy against a ones operand) instead of fp32 register sums: same addends, another summation order
+            # (with a row scale its addends are the bf16-rounded scaled values: 2^-9 relative each, random in sign)
+            db_ok = eq(db, db0) if io != 3 else float((db - db0).abs().max()) <= (6e-3 if with_rs else 1e-5) * float(db0.abs().max())
+            assert eq(dw, dw0) and db_ok, ("wgrad", io, with_rs)
     # flags outside the contract are refused, not ignored
     from cswin_unet_amd._lib import CswinHipError
     with pytest.raises(CswinHipError):
