@@ -1183,6 +1183,25 @@ def test_use_chk_with_drop_path_matches_plain_backward(N, ops):
         assert torch.allclose(grads[0][n], grads[1][n], rtol=1e-5, atol=1e-7), n
 
 
+def test_use_chk_in_bf16_mode_matches_plain_backward(N, ops, bf16_matmul):
+    """The same in the bf16 mode: the recompute runs the bf16-storage forward again, the backward finds (or does not find) the bf16
+    gradient twins in another order than without checkpointing; with identical DropPath draws the gradients must agree to the
+    summation-order noise of the kernels (twin hits only choose between two kernels computing the same product)."""
+    img = T(det_normal("chk16.x", (2, 3, 224, 224)))
+    lab = T(det_labels("chk16.lab", (2, 224, 224), 9))
+    grads = []
+    for chk in (False, True):
+        net = N.CSWinTransformer(img_size=224, num_classes=9, embed_dim=64, depth=[1, 2, 2, 1], split_size=[1, 2, 7, 7],
+                                 num_heads=[2, 4, 8, 16], qkv_bias=True, drop_path_rate=0.3, use_chk=chk).to(DEV)
+        fill_state_dict(net).train()
+        torch.manual_seed(78)
+        loss, _ = ops.ce_dice_loss(net(img), lab)
+        loss.backward()
+        grads.append({n: p.grad.clone() for n, p in net.named_parameters()})
+    for n in grads[0]:
+        assert _rel_l2(grads[1][n], grads[0][n]) < 2e-2, (n, _rel_l2(grads[1][n], grads[0][n]))
+
+
 def test_out_of_range_label_poisons_the_loss(ops):
     """nn.CrossEntropyLoss raises on a target outside [0, ncls); the fused loss makes the step's loss NaN instead of silently
     biasing it (no host sync on the step path)."""
