@@ -53,6 +53,34 @@ constexpr int W16_SC_BYTES = (W16_SC_SAMPLES + W16_DMA_S * W16_MS) * 4;
 constexpr int W16_LDS = W16_DMA_S * W16_STEP + W16_SC_BYTES;        // 48.6 KB (register path: 2 stages + bias sums = 36 KB): 3 workgroups per CU
 static_assert(W16_LDS >= 2 * W16_STEP + 8 * W16_T * 4, "the register path's stages and bias sums must fit");
 
+// Partial 64 x 64 wave tile -> slab.  The 32x32 accumulators hold a COLUMN per lane (lane = k, registers = rows n): stored from
+// that layout a wave issues 64 dword stores.  Each fragment goes through a private [32][36] LDS patch instead (as the GEMM
+// epilogue does) so that a lane owns 4 consecutive k of one row: 16 stores of 16 B.  Call after a workgroup barrier (the patches
+// overlay the operand images); K % 4 == 0 and 16-B aligned slabs are the caller's contract.
+constexpr int W16_PATCH = 32 * 36;
+__device__ __forceinline__ void w16_store_tile(f32x16 (&acc)[2][2], float* slab, int N, int K, int n0, int k0, int lane, float* patch) {
+    const int li = lane & 31, lh = lane >> 5, rrow = lane >> 3, rcol = (lane & 7) * 4;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) patch[((g & 3) + 8 * (g >> 2) + 4 * lh) * 36 + li] = acc[a][c][g];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int k = k0 + 32 * c + rcol;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + 32 * a + rrow + 8 * q;
+                if (n < N && k < K) *reinterpret_cast<f32x4*>(slab + (long)n * K + k) = *reinterpret_cast<const f32x4*>(&patch[(rrow + 8 * q) * 36 + rcol]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+}
+
 // One problem's tile.  DY16 / X16: that operand is STORED as bf16 -- compile-time copies of the body (chosen per workgroup in
 // the kernel below): a run-time choice between 8-B and 16-B loads inside fetch() makes the prefetch loads wait for one another.
 template <bool DY16, bool X16>
@@ -177,19 +205,10 @@ __device__ __forceinline__ void wgrad16_tile(const W16Problem& P, const int lb, 
     }
 
     if (st && threadIdx.x == 0) st[2] = __builtin_amdgcn_s_memtime();
-    // ---- partial tile -> slab (C/D layout: lane = column k, registers = rows n) ----
+    // ---- partial tile -> slab ----
     float* slab = P.slab + (long)split * P.slab_stride;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int k = kb + 64 * wj + 32 * c + li;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int n = nb + 64 * wi + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * lh;
-                if (n < P.N && k < P.K) slab[(long)n * P.K + k] = acc[a][c][g];
-            }
-        }
+    __syncthreads();                        // every wave is done with the operand images: they become the store patches
+    w16_store_tile(acc, slab, P.N, P.K, nb + 64 * wi, kb + 64 * wj, lane, reinterpret_cast<float*>(lds) + wave * W16_PATCH);
     // ---- bias gradient partial: column sums of the dy tile (only the k-tile 0 workgroups own them) ----
     if (P.has_bias && kb == 0) {
         float* red = reinterpret_cast<float*>(lds + 2 * 2 * W16_MS * 256);      // [8][128]
@@ -340,17 +359,8 @@ __device__ __forceinline__ void wgrad16_dma_tile(const W16Problem& P, const int 
     }
     if (st && threadIdx.x == 0) st[2] = __builtin_amdgcn_s_memtime();
     float* slab = P.slab + (long)split * P.slab_stride;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int k = kb + 64 * wj + 32 * c + li;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int n = nb + 64 * wi + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * lh;
-                if (n < P.N && k < P.K) slab[(long)n * P.K + k] = acc[a][c][g];
-            }
-        }
+    w16_barrier();                          // every wave is done with the operand images: they become the store patches
+    w16_store_tile(acc, slab, P.N, P.K, nb + 64 * wi, kb + 64 * wj, lane, reinterpret_cast<float*>(lds) + wave * W16_PATCH);
     if (do_bias && li == 0) {               // every column of the ones product holds the row sums: take column 0
 #pragma unroll
         for (int a = 0; a < 2; ++a)
