@@ -57,18 +57,23 @@ __device__ __forceinline__ void g16_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // KG: k-groups.  KG = 2 (long reductions with about one workgroup per CU, where a workgroup's life IS the kernel time): eight
 // waves; wave group g takes the 64-k steps 2 i + g, a ring slot holds a PAIR of steps, the two accumulator sets meet in LDS
 // before the epilogue (run by group 0).  The loop is half as long for the same bytes and instructions.
-template <int EPI, bool BT, int S, bool PRE16, int KG>
-__global__ __launch_bounds__(256 * KG) void gemm16_kernel(G16Params p) {
+// MODE 2: a 128 x 64 tile on eight waves (outputs with many tiles: half the workgroups to dispatch, the W tile shared by twice
+// the rows); a ring slot is the 16-KB A image + the 8-KB W image.
+template <int EPI, bool BT, int S, bool PRE16, int MODE>
+__global__ __launch_bounds__(MODE == 0 ? 256 : 512) void gemm16_kernel(G16Params p) {
+    constexpr int KG = MODE == 1 ? 2 : 1;            // k-groups
+    constexpr int TM = MODE == 2 ? 2 * G16_T : G16_T;  // tile rows
     extern __shared__ __attribute__((aligned(16))) unsigned char g16_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wave8 & 3, kgrp = wave8 >> 2;
+    const int wave = MODE == 2 ? wave8 : (wave8 & 3), kgrp = MODE == 1 ? (wave8 >> 2) : 0;
     const int li = lane & 31, lh = lane >> 5;
-    constexpr int SLOT = KG * G16_STAGE;             // bytes of a ring slot
+    constexpr int A_IMG = TM * 128;                  // bytes of the A image of a step
+    constexpr int SLOT = KG * (A_IMG + G16_IMG);     // bytes of a ring slot
     // XCD-aware block order (as gemm.hip): each XCD takes a contiguous range of tiles, ordered [m-tile][n-tile]
     const int bid = blockIdx.x, xq = p.nblk >> 3, xr = p.nblk & 7, xcd = bid & 7;
     const int lb = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const int m0 = (lb / p.tiles_n) * G16_T, n0 = (lb % p.tiles_n) * G16_T;
-    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int m0 = (lb / p.tiles_n) * TM, n0 = (lb % p.tiles_n) * G16_T;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;         // MODE 2: wave 0 .. 7 -> rows 0 .. 96
     const int nsteps = p.R / (G16_T * KG);           // loop iterations (KG steps of 64 each)
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)g16_lds;   // LDS byte address of the ring
 
@@ -79,21 +84,28 @@ __global__ __launch_bounds__(256 * KG) void gemm16_kernel(G16Params p) {
     const unsigned char* b_src[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const int row = (KG == 2 ? wave8 : 2 * wave + g) * 8 + drow;     // row of the image
+        const int row = (KG == 2 ? wave8 : 2 * wave + g) * 8 + drow;     // row of the A image
+        const int brow = MODE == 2 ? wave8 * 8 + drow : row;             // row of the W image (MODE 2: one group per wave)
         const int ca = slot ^ ((row >> 1) & 7);                          // source chunk of this lane's slot
         const int am = min(m0 + row, p.M - 1);                           // clamped rows are never stored
         a_src[g] = reinterpret_cast<const unsigned char*>(p.A + (long)am * p.lda + 8 * ca);
         if (!BT) {
-            const int bn = min(n0 + row, p.NO - 1);
-            b_src[g] = reinterpret_cast<const unsigned char*>(p.B + (long)bn * p.ldb + 8 * ca);
+            const int bn = min(n0 + brow, p.NO - 1);
+            b_src[g] = reinterpret_cast<const unsigned char*>(p.B + (long)bn * p.ldb + 8 * (slot ^ ((brow >> 1) & 7)));
         } else {
-            int cb = slot ^ (((row >> 1) & 1) << 2);
+            int cb = slot ^ (((brow >> 1) & 1) << 2);
             cb = min(cb, (p.NO - n0) / 8 - 1);                           // columns beyond NO: any in-range chunk (never stored)
-            b_src[g] = reinterpret_cast<const unsigned char*>(p.B + (long)row * p.ldb + n0 + 8 * cb);
+            b_src[g] = reinterpret_cast<const unsigned char*>(p.B + (long)brow * p.ldb + n0 + 8 * cb);
         }
     }
     auto issue = [&](int it) {
-        if constexpr (KG == 1) {
+        if constexpr (MODE == 2) {
+            const unsigned st = lds0 + (unsigned)(it % S) * SLOT;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) g16_dma(a_src[g] + (long)it * (G16_T * 2), st + (unsigned)wave8 * 2048 + g * 1024);
+            const unsigned char* src = BT ? b_src[0] + (long)it * G16_T * p.ldb * 2 : b_src[0] + (long)it * (G16_T * 2);
+            g16_dma(src, st + A_IMG + (unsigned)wave8 * 1024);
+        } else if constexpr (KG == 1) {
             const unsigned st = lds0 + (unsigned)(it % S) * SLOT + (unsigned)wave * 2048;
 #pragma unroll
             for (int g = 0; g < 2; ++g) g16_dma(a_src[g] + (long)it * (G16_T * 2), st + g * 1024);
@@ -148,14 +160,15 @@ __global__ __launch_bounds__(256 * KG) void gemm16_kernel(G16Params p) {
     for (int step = 0; step < nsteps; ++step) {
         // this step's 4 DMAs (per wave) have landed when at most 4 * (groups issued after it) are outstanding
         const int later = min(S - 2, nsteps - 1 - step);
-        if (S >= 4 && later >= 2) g16_wait<8>();
-        else if (S >= 3 && later >= 1) g16_wait<4>();
+        constexpr int PW = MODE == 2 ? 3 : 4;          // DMAs per wave and iteration
+        if (S >= 4 && later >= 2) g16_wait<2 * PW>();
+        else if (S >= 3 && later >= 1) g16_wait<PW>();
         else g16_wait<0>();
         g16_barrier();                     // every wave's part of the step is in LDS; the stage read in step - 1 is free again
         if (step + S - 1 < nsteps) issue(step + S - 1);
         if (stamps && tid == 0 && step == 0) stamps[8L * bid + 1] = __builtin_amdgcn_s_memtime();
         const unsigned char* aimg = g16_lds + (step % S) * SLOT + kgrp * G16_STAGE;
-        const unsigned char* bimg = aimg + G16_IMG;
+        const unsigned char* bimg = aimg + A_IMG;
 #pragma unroll
         for (int kk = 0; kk < G16_T; kk += 16) {
             const int c = (kk >> 3) + lh;                                 // 16-B chunk of this lane's 8 reduction values
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(256 * KG) void gemm16_kernel(G16Params p) {
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc0[g] += xch[g * 64 + lane];
     }
-    float* wbuf = reinterpret_cast<float*>(g16_lds) + wave * EP_WAVE_FLOATS;
+    float* wbuf = reinterpret_cast<float*>(g16_lds) + wave * EP_WAVE_FLOATS;      // MODE 2: eight patches (wave = 0 .. 7)
 #pragma unroll
     for (int g = 0; g < 16; ++g) wbuf[((g & 3) + 8 * (g >> 2) + 4 * lh) * EP_LD + li] = acc0[g];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -235,6 +248,8 @@ int g16_launch(const G16Params& p, hipStream_t st) {
     // 11.3 k cycles, kernel span 10.0 -> 7.7 us), inside the step it does not pay (7.57 against 7.51 ms/step, twice each):
     // opt-in only (CSWIN_GEMM16_KG=2 applies it where nsteps >= 8 and nblk <= 400).
     const bool kg2 = forced_kg == 2 && nsteps >= 8 && nsteps % 2 == 0 && p.nblk <= 400;
+    static const int forced_tm = getenv("CSWIN_GEMM16_TM") ? atoi(getenv("CSWIN_GEMM16_TM")) : 0;           // tuning aid: 64 / 128
+    const bool tm128 = !kg2 && (forced_tm == 128 || (forced_tm == 0 && p.nblk > 768));
     int S = nsteps >= 3 ? 3 : 2;          // 48 KB: three workgroups per CU (measured against 2 and 4 stages: profiles/round2_notes.md)
     if (forced >= 2 && forced <= 4) S = forced;
     static_assert(2 * G16_STAGE >= 4 * EP_WAVE_FLOATS * (int)sizeof(float), "the smallest ring must hold the epilogue patches");
@@ -243,19 +258,27 @@ int g16_launch(const G16Params& p, hipStream_t st) {
     static std::once_flag once;
     static hipError_t status = hipSuccess;
     std::call_once(once, [&] {
-        status = hipFuncSetAttribute((const void*)gemm16_kernel<EPI, BT, 4, PRE16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G16_STAGE);
-        if (status == hipSuccess) status = hipFuncSetAttribute((const void*)gemm16_kernel<EPI, BT, 3, PRE16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * G16_STAGE);
-        if (status == hipSuccess) status = hipFuncSetAttribute((const void*)gemm16_kernel<EPI, BT, 2, PRE16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G16_STAGE);
+        status = hipFuncSetAttribute((const void*)gemm16_kernel<EPI, BT, 4, PRE16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G16_STAGE);
+        if (status == hipSuccess) status = hipFuncSetAttribute((const void*)gemm16_kernel<EPI, BT, 3, PRE16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * G16_STAGE);
+        if (status == hipSuccess) status = hipFuncSetAttribute((const void*)gemm16_kernel<EPI, BT, 2, PRE16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G16_STAGE);
+        if (status == hipSuccess) status = hipFuncSetAttribute((const void*)gemm16_kernel<EPI, BT, 3, PRE16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (3 * G16_IMG));
     });
     if (status != hipSuccess) return 1;
     if (kg2) {                             // two ring slots of two steps each: 64 KB, two workgroups per CU
-        hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 2, PRE16, 2>), dim3(p.nblk), dim3(512), 4 * G16_STAGE, st, p);
+        hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 2, PRE16, 1>), dim3(p.nblk), dim3(512), 4 * G16_STAGE, st, p);
+        return 0;
+    }
+    if (tm128) {                           // 128 x 64 tiles: three slots of 24 KB, two workgroups per CU
+        G16Params q = p;
+        q.tiles_m = cdiv(p.M, 2 * G16_T);
+        q.nblk = q.tiles_m * q.tiles_n;
+        hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 3, PRE16, 2>), dim3(q.nblk), dim3(512), 3 * (3 * G16_IMG), st, q);
         return 0;
     }
     const size_t lds = (size_t)S * G16_STAGE;
-    if (S == 4) hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 4, PRE16, 1>), dim3(p.nblk), dim3(256), lds, st, p);
-    else if (S == 3) hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 3, PRE16, 1>), dim3(p.nblk), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 2, PRE16, 1>), dim3(p.nblk), dim3(256), lds, st, p);
+    if (S == 4) hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 4, PRE16, 0>), dim3(p.nblk), dim3(256), lds, st, p);
+    else if (S == 3) hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 3, PRE16, 0>), dim3(p.nblk), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 2, PRE16, 0>), dim3(p.nblk), dim3(256), lds, st, p);
     return 0;
 }
 
