@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_BF16_MATRIX_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA dense peak (~2.5 PF; 16 x the fp32 matrix rate)
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -55,7 +56,7 @@ def _graph_time(fn, reps=20, rounds=5):
     return best
 
 
-def attention_roofline(batch, cfg, img_size=224):
+def attention_roofline(batch, cfg, img_size=224, bf16=False):
     """Times the fused stripe-attention kernels for the four stage shapes of the model at this batch through the C ABI.
     Algorithmic FLOPs: QK^T + PV = 4*L*N*C per block per image forward; backward = 2x that (dQ, dK, dV, dP).
     Algorithmic bytes: q,k,v in + y out = 16*L*C per block per image forward; backward q,k,v,dy in + dqkv out = 28*L*C."""
@@ -74,11 +75,13 @@ def attention_roofline(batch, cfg, img_size=224):
         hb = [heads[si]] if single else [heads[si] // 2] * 2
         nb, cb = len(idx), C // len(idx)
         n_tok = reso * reso if single else reso * split[si]
-        qkv = torch.randn(batch, L, 3 * C, generator=g).to(dev)
+        # bf16 mode: q / k / v / y / dqkv stored as bf16 and bf16 matrix instructions (attention storage mode 7), as the model runs it
+        mode, adt = (7, torch.bfloat16) if bf16 else (0, torch.float32)
+        qkv = torch.randn(batch, L, 3 * C, generator=g).to(dev).to(adt)
         w = [(torch.randn(cb, 9, generator=g) / 3).to(dev) for _ in idx]
         b = [(torch.randn(cb, generator=g) * 0.02).to(dev) for _ in idx]
         dy = torch.randn(batch, L, C, generator=g).to(dev)
-        y = torch.empty(batch, L, C, device=dev)
+        y = torch.empty(batch, L, C, device=dev, dtype=adt)
         lse = torch.empty(batch, sum(hb), L, device=dev)
         dqkv = torch.empty_like(qkv)
         dw, db = [torch.empty_like(t) for t in w], [torch.empty_like(t) for t in b]
@@ -87,12 +90,14 @@ def attention_roofline(batch, cfg, img_size=224):
         nbytes = lib().cswin_attn_bwd_workspace(batch, reso, C, nb, ha, ia, split[si])
         ws = torch.empty(nbytes // 4 + 4, device=dev)
         t_f = _graph_time(lambda: call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(lse), batch, reso, C, nb, ha, ia,
-                                       split[si], 0.0, 0.0, 0, 0, stream()))
+                                       split[si], 0.0, 0.0, 0, mode, stream()))
         t_b = _graph_time(lambda: call("cswin_attn_bwd", ptr(qkv), pa(w), pa(b), ptr(lse), ptr(y), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws),
-                                       nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, None, 0.0, 0, 0, stream()))
+                                       nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, None, 0.0, 0, mode, stream()))
         flops_f = 4.0 * L * n_tok * C * batch
         n_blocks = 2 * depth[si]
         bytes_f, bytes_b = 16.0 * L * C * batch, 28.0 * L * C * batch
+        if bf16:                                   # q, k, v, y, dqkv at 2 B; dy stays fp32
+            bytes_f, bytes_b = 8.0 * L * C * batch, 18.0 * L * C * batch
         rows.append({"stage": si + 1, "window_tokens": n_tok, "launches_per_step": n_blocks,
                      "fwd_us": round(t_f * 1e6, 2), "bwd_us": round(t_b * 1e6, 2),
                      "fwd_tflops": round(flops_f / t_f / 1e12, 2), "bwd_tflops": round(2 * flops_f / t_b / 1e12, 2),
@@ -106,12 +111,13 @@ def attention_roofline(batch, cfg, img_size=224):
     # the profiled configuration (224x224, batch 24).
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "round1_attn_pmc.json")
-    if batch == 24 and img_size == 224 and os.path.exists(pmc):
+    if batch == 24 and img_size == 224 and os.path.exists(pmc) and not bf16:
         per = json.load(open(pmc))["per_launch"]
         traffic = int(sum(2 * depth[si] * (per[f"stage{si + 1}"]["fwd_bytes"] + per[f"stage{si + 1}"]["bwd_bytes"]) for si in range(4)))
     return {"kernel": "attn_fwd_kernel + attn_bwd_kernel / attn_bwd2_kernel (+ their slab reduction launch), all 26 blocks of one step", "bound": "mfma",
-            "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic,
+            "achieved": round(achieved, 2), "peak": PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / (PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS), 4), "traffic": traffic,
+            "matrix_instructions": "bf16 (v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16), fp32 accumulate" if bf16 else "fp32 (v_mfma_f32_16x16x4_f32)",
             "traffic_note": "bytes per step (52 launches); algorithmic bytes per step = %d" % int(tot_bytes),
             "algorithmic_gflop_per_step": round(tot_flops / 1e9, 2), "time_per_step_ms": round(tot_time * 1e3, 3),
             "hbm_frac_algorithmic": round(tot_bytes / tot_time / 1e9 / PEAK_HBM_GBPS, 4), "per_stage": rows}
@@ -310,7 +316,7 @@ def main():
                "model_tflops": round(33.2e9 * world * args.batch * args.steps / elapsed / 1e12, 2) if config.DATA.IMG_SIZE == 224 and config.MODEL.CSWIN.EMBED_DIM == 64 else None}
         if world == 1 and not args.skip_roofline:
             log("[bench] attention roofline sub-benchmark ...")
-            out["roofline"] = attention_roofline(args.batch, config.MODEL.CSWIN, config.DATA.IMG_SIZE)
+            out["roofline"] = attention_roofline(args.batch, config.MODEL.CSWIN, config.DATA.IMG_SIZE, bf16=args.matmul == "bf16")
             if args.matmul == "fp32":
                 log("[bench] GEMM family roofline sub-benchmark ...")
                 out["roofline_dominant_by_time"] = gemm_family_roofline(args.batch, config.MODEL.CSWIN, config.DATA.IMG_SIZE)
