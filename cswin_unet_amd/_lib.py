@@ -101,13 +101,22 @@ def set_act_bf16(on):
 _shadows = []
 
 
-def register_shadow(owner, shadow, refresh, params):
-    """`shadow` (bf16, same numel) mirrors the fp32 buffer `owner` that the tensors `params` alias.  The update kernel writes
-    both; a write from anywhere else (load_state_dict, a manual copy_) bumps the parameter's version counter, which
-    shadow_ptr() notices on the next use of that weight and answers with one refresh() of the whole shadow."""
-    _shadows[:] = [e for e in _shadows if e[0] != owner.data_ptr()]
-    params = list(params)
-    _shadows.append([owner.data_ptr(), owner.numel() * 4, shadow, refresh, {p.data_ptr(): p._version for p in params}, params])
+class _Shadow:
+    """One registered bf16 shadow.  Holds its owner weakly: when the optimiser (and with it the flat buffers) goes away the
+    entry dies with it instead of keeping the model's memory alive."""
+
+    def __init__(self, owner_obj, owner, seen):
+        import weakref
+        self.ref = weakref.ref(owner_obj)             # the object that has .flat_param16 / .refresh_shadow / .params
+        self.base, self.nbytes, self.seen = owner.data_ptr(), owner.numel() * 4, seen
+
+
+def register_shadow(owner_obj, owner):
+    """owner_obj.flat_param16 (bf16, same numel) mirrors the fp32 buffer `owner` that the tensors owner_obj.params alias.  The
+    update kernel writes both; a write from anywhere else (load_state_dict, a manual copy_) bumps the parameter's version
+    counter, which shadow_ptr() notices on the next use of that weight and answers with one owner_obj.refresh_shadow()."""
+    _shadows[:] = [e for e in _shadows if e.ref() is not None and e.base != owner.data_ptr()]
+    _shadows.append(_Shadow(owner_obj, owner, {p.data_ptr(): p._version for p in owner_obj.params}))
 
 
 def shadow_ptr(w):
@@ -115,14 +124,17 @@ def shadow_ptr(w):
     if not _shadows or w is None:
         return None
     a = w.data_ptr()
-    for base, nbytes, shadow, refresh, seen, params in _shadows:
-        if base <= a < base + nbytes:
-            if seen.get(a) != w._version:
-                refresh()
-                seen.clear()
-                seen.update({p.data_ptr(): p._version for p in params})
-                seen[a] = w._version
-            return c_void_p(shadow.data_ptr() + (a - base) // 2)
+    for e in _shadows:
+        if e.base <= a < e.base + e.nbytes:
+            opt = e.ref()
+            if opt is None:
+                return None
+            if e.seen.get(a) != w._version:
+                opt.refresh_shadow()
+                e.seen.clear()
+                e.seen.update({p.data_ptr(): p._version for p in opt.params})
+                e.seen[a] = w._version
+            return c_void_p(opt.flat_param16.data_ptr() + (a - e.base) // 2)
     return None
 
 
@@ -131,7 +143,9 @@ def set_precision(mode):
     _state["precision"] = int(mode)
     if int(mode) == PREC_BF16 and prev != PREC_BF16:
         for e in _shadows:                   # the optimiser only maintains the bf16 shadow while the bf16 mode is on
-            e[3]()
+            opt = e.ref()
+            if opt is not None:
+                opt.refresh_shadow()
     return prev
 
 

@@ -40,7 +40,7 @@ class FlatSGD:
         # weights in every GEMM); written by the update kernel, re-packed when something else writes the parameters
         self.flat_param16 = torch.empty(off, dtype=torch.bfloat16, device=dev)
         self.refresh_shadow()
-        register_shadow(self.flat_param, self.flat_param16, self.refresh_shadow, self.params)
+        register_shadow(self, self.flat_param)
         self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
         self.lr = float(lr)
         # gather tables: one {src, dst, n} record per <= 16 Ki-float chunk, per gathered parameter range
