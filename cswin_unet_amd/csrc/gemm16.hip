@@ -18,7 +18,8 @@
 //     the MFMA fragments are ds_read_b128 (8 reduction values of one row), conflict free.
 //   W of the data gradient (rows = reduction index n, 64 output columns k each): slot c ^ (4 * ((r >> 1) & 1)), the image gemm.hip
 //     uses for its transposing reads (ds_read_b64_tr_b16 delivers the reduction-contiguous fragments).
-// One workgroup = 4 waves = one 64 x 64 output tile (wave: 32 x 32); epilogue shared with the tiled family (gemm_epilogue.h).
+// One workgroup = 4 waves = one 64 x 64 output tile (wave: 32 x 32), or 8 waves = 128 x 64 where there are many tiles.  Reduction
+// lengths n x 64 or n x 64 + 32 (cswin_base: C = 96): a half last step rereads in-range chunks and skips its upper two MFMAs.
 #include <mutex>
 #include <type_traits>
 #include "common.h"
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512) void gemm16_kernel(G16Params
     const int lb = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int m0 = (lb / p.tiles_n) * TM, n0 = (lb % p.tiles_n) * G16_T;
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;         // MODE 2: wave 0 .. 7 -> rows 0 .. 96
-    const int nsteps = p.R / (G16_T * KG);           // loop iterations (KG steps of 64 each)
+    const int nsteps = (p.R + G16_T * KG - 1) / (G16_T * KG);        // loop iterations (KG steps of 64 each)
+    const int tail = p.R % G16_T;                    // 0, or 32 valid reduction values in the last step (KG = 1 only)
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)g16_lds;   // LDS byte address of the ring
 
     // ---- DMA source addresses.  KG = 1: wave w moves row groups 2w and 2w + 1 (8 rows each) of both images of a step;
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512) void gemm16_kernel(G16Params
     const int drow = lane >> 3, slot = lane & 7;
     const unsigned char* a_src[2];
     const unsigned char* b_src[2];
+    int a_td[2], b_td[2];                            // byte deltas of the sources for a half last step: stay inside the row / the matrix
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int row = (KG == 2 ? wave8 : 2 * wave + g) * 8 + drow;     // row of the A image
@@ -89,30 +92,35 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512) void gemm16_kernel(G16Params
         const int ca = slot ^ ((row >> 1) & 7);                          // source chunk of this lane's slot
         const int am = min(m0 + row, p.M - 1);                           // clamped rows are never stored
         a_src[g] = reinterpret_cast<const unsigned char*>(p.A + (long)am * p.lda + 8 * ca);
+        a_td[g] = 16 * ((ca & 3) - ca);             // chunks 4 .. 7 of a half step lie beyond the row: reread 0 .. 3 (never used)
         if (!BT) {
             const int bn = min(n0 + brow, p.NO - 1);
-            b_src[g] = reinterpret_cast<const unsigned char*>(p.B + (long)bn * p.ldb + 8 * (slot ^ ((brow >> 1) & 7)));
+            const int cbf = slot ^ ((brow >> 1) & 7);
+            b_src[g] = reinterpret_cast<const unsigned char*>(p.B + (long)bn * p.ldb + 8 * cbf);
+            b_td[g] = 16 * ((cbf & 3) - cbf);
         } else {
+            b_td[g] = (int)((long)((brow & 31) - brow) * p.ldb * 2);      // rows 32 .. 63 of a half step lie beyond the matrix
             int cb = slot ^ (((brow >> 1) & 1) << 2);
             cb = min(cb, (p.NO - n0) / 8 - 1);                           // columns beyond NO: any in-range chunk (never stored)
             b_src[g] = reinterpret_cast<const unsigned char*>(p.B + (long)brow * p.ldb + n0 + 8 * cb);
         }
     }
     auto issue = [&](int it) {
+        const bool half = tail != 0 && it == nsteps - 1;                  // wave-uniform
         if constexpr (MODE == 2) {
             const unsigned st = lds0 + (unsigned)(it % S) * SLOT;
 #pragma unroll
-            for (int g = 0; g < 2; ++g) g16_dma(a_src[g] + (long)it * (G16_T * 2), st + (unsigned)wave8 * 2048 + g * 1024);
+            for (int g = 0; g < 2; ++g) g16_dma(a_src[g] + (long)it * (G16_T * 2) + (half ? a_td[g] : 0), st + (unsigned)wave8 * 2048 + g * 1024);
             const unsigned char* src = BT ? b_src[0] + (long)it * G16_T * p.ldb * 2 : b_src[0] + (long)it * (G16_T * 2);
-            g16_dma(src, st + A_IMG + (unsigned)wave8 * 1024);
+            g16_dma(src + (half ? b_td[0] : 0), st + A_IMG + (unsigned)wave8 * 1024);
         } else if constexpr (KG == 1) {
             const unsigned st = lds0 + (unsigned)(it % S) * SLOT + (unsigned)wave * 2048;
 #pragma unroll
-            for (int g = 0; g < 2; ++g) g16_dma(a_src[g] + (long)it * (G16_T * 2), st + g * 1024);
+            for (int g = 0; g < 2; ++g) g16_dma(a_src[g] + (long)it * (G16_T * 2) + (half ? a_td[g] : 0), st + g * 1024);
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const unsigned char* src = BT ? b_src[g] + (long)it * G16_T * p.ldb * 2 : b_src[g] + (long)it * (G16_T * 2);
-                g16_dma(src, st + G16_IMG + g * 1024);
+                g16_dma(src + (half ? b_td[g] : 0), st + G16_IMG + g * 1024);
             }
         } else {
             const unsigned st = lds0 + (unsigned)(it % S) * SLOT + (unsigned)wave8 * 1024;
@@ -169,8 +177,10 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512) void gemm16_kernel(G16Params
         if (stamps && tid == 0 && step == 0) stamps[8L * bid + 1] = __builtin_amdgcn_s_memtime();
         const unsigned char* aimg = g16_lds + (step % S) * SLOT + kgrp * G16_STAGE;
         const unsigned char* bimg = aimg + A_IMG;
+        const int kend = (tail != 0 && step == nsteps - 1) ? tail : G16_T;      // a half last step holds 32 reduction values
 #pragma unroll
         for (int kk = 0; kk < G16_T; kk += 16) {
+            if (kk >= kend) break;
             const int c = (kk >> 3) + lh;                                 // 16-B chunk of this lane's 8 reduction values
             const int ar = wm0 + li;
             const g16_bf16x8 af = *reinterpret_cast<const g16_bf16x8*>(aimg + ar * 128 + 16 * (c ^ ((ar >> 1) & 7)));
@@ -241,13 +251,13 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512) void gemm16_kernel(G16Params
 
 template <int EPI, bool BT, bool PRE16>
 int g16_launch(const G16Params& p, hipStream_t st) {
-    const int nsteps = p.R / G16_T;
+    const int nsteps = (p.R + G16_T - 1) / G16_T;
     static const int forced = getenv("CSWIN_GEMM16_STAGES") ? atoi(getenv("CSWIN_GEMM16_STAGES")) : 0;      // tuning aid: 2 .. 4
     static const int forced_kg = getenv("CSWIN_GEMM16_KG") ? atoi(getenv("CSWIN_GEMM16_KG")) : 0;           // tuning aid: 1 / 2
     // Two k-groups for long reductions with about one workgroup per CU: stand-alone the workgroup life drops (K = 1024: 13.5 k ->
     // 11.3 k cycles, kernel span 10.0 -> 7.7 us), inside the step it does not pay (7.57 against 7.51 ms/step, twice each):
     // opt-in only (CSWIN_GEMM16_KG=2 applies it where nsteps >= 8 and nblk <= 400).
-    const bool kg2 = forced_kg == 2 && nsteps >= 8 && nsteps % 2 == 0 && p.nblk <= 400;
+    const bool kg2 = forced_kg == 2 && nsteps >= 8 && nsteps % 2 == 0 && p.R % G16_T == 0 && p.nblk <= 400;
     static const int forced_tm = getenv("CSWIN_GEMM16_TM") ? atoi(getenv("CSWIN_GEMM16_TM")) : 0;           // tuning aid: 64 / 128
     const bool tm128 = !kg2 && (forced_tm == 128 || (forced_tm == 0 && p.nblk > 768));
     int S = nsteps >= 3 ? 3 : 2;          // 48 KB: three workgroups per CU (measured against 2 and 4 stages: profiles/round2_notes.md)
@@ -289,7 +299,7 @@ int g16_launch(const G16Params& p, hipStream_t st) {
 // Returns 0 when launched, 1 when the shape is not covered (the caller falls back to the tiled family).
 int cswin_gemm16(int mode, int epi_mode, const void* A, const void* B, const void* epilogue, int M, int NO, int R, void* stream) {
     static const bool off = getenv("CSWIN_GEMM16") && atoi(getenv("CSWIN_GEMM16")) == 0;                    // tuning aid
-    if (off || R % G16_T != 0 || NO % 8 != 0 || M < 1) return 1;
+    if (off || (R % G16_T != 0 && R % G16_T != 32) || R < G16_T || NO % 8 != 0 || M < 1) return 1;    // reduction: n x 64 (+ 32)
     if ((((uintptr_t)A) | ((uintptr_t)B)) & 15) return 1;
     G16Params p;
     p.A = (const __bf16*)A; p.lda = R;

@@ -802,7 +802,7 @@ def _bf16_step_vs_oracle(N, ops, cfg, net, img, lab, tag, grads):
         assert e < BF16_GRAD_L2, (n, e)
 
 
-@pytest.mark.parametrize("M,Nn,K", [(4704, 768, 256), (1176, 512, 2048), (3000, 64, 64), (100, 72, 64), (37, 8, 128), (160, 200, 192)])
+@pytest.mark.parametrize("M,Nn,K", [(4704, 768, 256), (1176, 512, 2048), (3000, 64, 64), (100, 72, 64), (37, 8, 128), (160, 200, 192), (1000, 288, 96), (333, 96, 32)])
 def test_linear_bf16_storage_flags_bit_exact(M, Nn, K):
     """io_bf16 of cswin_linear_fwd / cswin_linear_bwd_data / cswin_wgrad_desc (include/cswin_hip.h): a tensor STORED as bf16 must
     give bit-identical results to the same values held in fp32 (the operands are rounded to bf16 either way, and a bf16 -> fp32
