@@ -107,10 +107,12 @@ def attention_roofline(batch, cfg, img_size=224, bf16=False):
         tot_bytes += n_blocks * (bytes_f + bytes_b)
     achieved = tot_flops / tot_time / 1e12
     # HBM bytes of the same 52 launches from PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
-    # FETCH_SIZE doubled per MI355X_MICROARCH.md; tools/attn_one.py -> profiles/round1_attn_pmc.json).  Only valid for
+    # FETCH_SIZE doubled per MI355X_MICROARCH.md; tools/attn_pmc.sh -> profiles/round2_attn_pmc.json).  Only valid for
     # the profiled configuration (224x224, batch 24).
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "round1_attn_pmc.json")
+    pmc = os.path.join(ROOT, "profiles", "round2_attn_pmc.json")
+    if not os.path.exists(pmc):
+        pmc = os.path.join(ROOT, "profiles", "round1_attn_pmc.json")
     if batch == 24 and img_size == 224 and os.path.exists(pmc) and not bf16:
         per = json.load(open(pmc))["per_launch"]
         traffic = int(sum(2 * depth[si] * (per[f"stage{si + 1}"]["fwd_bytes"] + per[f"stage{si + 1}"]["bwd_bytes"]) for si in range(4)))
