@@ -520,6 +520,38 @@ def test_trainer_three_steps_vs_golden(N, golden, use_graph):
     assert abs(chk - float(g["sgd_weight_checksum"])) <= 1e-4 * float(g["sgd_weight_checksum"])
 
 
+def test_bf16_mode_training_tracks_fp32(N):
+    """BASELINE's metric pairs the throughput with "Dice vs ref": 25 SGD steps on a learnable synthetic task (the label of a pixel
+    is a function of its intensity) with the product trainer, once in fp32 and once in the bf16 mode (bf16 MFMAs incl. attention,
+    bf16 activation storage, weight shadow), same initial weights and data.  Both must learn (loss and the Dice term fall), and
+    the bf16 trajectory must stay within 1 % of the fp32 one at every step (measured: 0.3 %)."""
+    import cswin_unet_amd
+    from cswin_unet_amd.trainer import DataParallelTrainer
+    torch.manual_seed(0)
+    img = torch.randn(4, 1, 224, 224, device=DEV)
+    img = torch.nn.functional.avg_pool2d(img, 9, 1, 4)                      # smooth blobs
+    lab = torch.bucketize(img[:, 0], torch.tensor([-0.15, -0.05, 0.05, 0.15], device=DEV)).long()     # 5 classes by intensity
+    img3 = img.repeat(1, 3, 1, 1) * 5
+    traj = {}
+    for mode in ("fp32", "bf16"):
+        prev = cswin_unet_amd.set_matmul_precision(mode)
+        try:
+            net = N.CSWinTransformer(img_size=224, num_classes=9, embed_dim=64, depth=[1, 2, 2, 1], split_size=[1, 2, 7, 7],
+                                     num_heads=[2, 4, 8, 16], qkv_bias=True, drop_path_rate=0.).to(DEV)
+            fill_state_dict(net).train()
+            tr = DataParallelTrainer(net, 9, base_lr=0.05, max_iterations=1000, use_graph=True)
+            traj[mode] = np.array([[float(v) for v in tr.train_step(img3, lab)] for _ in range(25)])
+        finally:
+            cswin_unet_amd.set_matmul_precision(prev)
+    f, b = traj["fp32"], traj["bf16"]
+    with open(LOG, "a") as fh:
+        fh.write(f"bf16_tracks_fp32: loss fp32 {f[0, 0]:.4f} -> {f[-1, 0]:.4f}, bf16 {b[0, 0]:.4f} -> {b[-1, 0]:.4f}; "
+                 f"dice fp32 {f[0, 2]:.4f} -> {f[-1, 2]:.4f}, bf16 {b[0, 2]:.4f} -> {b[-1, 2]:.4f}; max rel dev {np.abs(b[:, 0] / f[:, 0] - 1).max():.3e}\n")
+    assert f[-1, 0] < 0.8 * f[0, 0] and b[-1, 0] < 0.8 * b[0, 0], (f[:, 0], b[:, 0])
+    assert f[-1, 2] < f[0, 2] and b[-1, 2] < b[0, 2]
+    assert np.abs(b[:, 0] / f[:, 0] - 1).max() < 1e-2, np.abs(b[:, 0] / f[:, 0] - 1)
+
+
 def test_trainer_rccl_path_single_rank(N, golden):
     """Same trajectory with the collectives actually issued (1-rank RCCL group: all-reduce is the identity): exercises the
     broadcast, the 28-float loss all-reduce between the hipGraphs and the per-phase bucketed gradient all-reduces."""
