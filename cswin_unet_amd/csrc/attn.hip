@@ -1224,8 +1224,8 @@ int launch_fwd_q(const AttnParams& p, int nwg, hipStream_t st) {
     }
     if constexpr (NT <= 8) {
         // few units relative to the 256 CUs: split the query tiles over two workgroups per unit (see the kernel)
-        static const char* force = getenv("CSWIN_ATTN_FWD_QSPLIT");                      // tuning aid: "1" or "2"
-        const bool split = force ? force[0] == '2' : (nwg < 1024 && nwg % 256 != 0 && NT >= 6);   // measured: pays at N = 98, not at N = 49
+        const int force = cswin_tuning().attn_fwd_qsplit;                                // tuning aid: 1 or 2
+        const bool split = force ? force == 2 : (nwg < 1024 && nwg % 256 != 0 && NT >= 6);   // measured: pays at N = 98, not at N = 49
         if (split) {
             hipLaunchKernelGGL((attn_fwd_kernel<NT, 2, Q16>), dim3(2 * nwg), dim3(64 * ((NT + 1) / 2)), lds, st, p, nwg);
             return CSWIN_OK;
@@ -1283,7 +1283,7 @@ void launch_bwd_two_pass(const AttnParams& p, long items, int nwg, int nblk, hip
 long long* g_attn_stamps = nullptr;     // debug only (cswin_debug_set_attn_stamps)
 
 inline bool force_two_pass() {          // tuning aid: the large-window backward for every window size
-    static const bool f = getenv("CSWIN_ATTN_BWD_TWO_PASS") != nullptr;
+    const bool f = cswin_tuning().attn_bwd_two_pass != 0;
     return f;
 }
 

@@ -408,7 +408,7 @@ int cswin_carafe_bwd(const float* dout, const float* z, const float* wt_save, fl
     const int groups = 256 / carafe_lpr(Cz);
     hipStream_t st = (hipStream_t)stream;
     const long items = (long)B * H * W * S * S, pixels = (long)B * H * W;
-    static const bool no_fused = getenv("CSWIN_CARAFE_GENERIC") != nullptr;                  // tuning aid
+    const bool no_fused = cswin_tuning().carafe_generic != 0;                                // tuning aid
     if (carafe4_fused_ok(H, W, Cz, S) && !no_fused) {
         const int tx = W / C4_T, ty = H / C4_T, nblk = B * tx * ty;
         hipLaunchKernelGGL(carafe4_bwd_fused_kernel, dim3(nblk), dim3(64 * C4_WAVES), 0, st, dout, z, wt_save, de, dz,

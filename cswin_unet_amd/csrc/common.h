@@ -1,5 +1,6 @@
 // Shared device/host helpers for libcswin_hip (gfx950 / CDNA4 only).
 #pragma once
+#include "tuning.h"
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>

@@ -584,7 +584,7 @@ void launch_cfg(const ASrc& A, const BSrc& B, const Epilogue& epi, int M, int N,
                 hipStream_t st) {
     int tm = cdiv(M, BM), tn = cdiv(N, BN);
     dim3 grid(tm * tn * splits);
-    static const int pad_lds = getenv("CSWIN_GEMM_PAD_LDS") ? atoi(getenv("CSWIN_GEMM_PAD_LDS")) : 0;   // tuning aid: caps residency
+    const int pad_lds = cswin_tuning().gemm_pad_lds;                                                    // tuning aid: caps residency
     hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, KW, A_RC, B_RC, VEC, EPI, SCALE_A, PREC, ASrc, BSrc>), grid, dim3(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KW), pad_lds, st, A, B, epi,
                        M, N, R, r_per_split, tm, tn);
 }
@@ -597,15 +597,15 @@ void launch_gemm(const ASrc& A, const BSrc& B, const Epilogue& epi_in, int M, in
     Epilogue epi = epi_in;
     epi.vec_store = epilogue_vec_ok(epi, N);
     auto blocks = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(N, bn) * splits; };
-    static const int forced_kw = getenv("CSWIN_GEMM_KW") ? atoi(getenv("CSWIN_GEMM_KW")) : 0;                    // tuning aid
+    const int forced_kw = cswin_tuning().gemm_kw;                                                               // tuning aid
     // Tile choice.  64 x 64 is the most efficient tile (profiles/round1_gemm_bench.txt), but every workgroup of these
     // launches is resident at once and the kernel ends with the most loaded CU: with t tiles the critical CU does
     // ceil(t / 256) of them.  When that is a poor multiple (stage 3: 296 tiles -> 2 where 1.16 would do) a smaller tile
     // shortens the critical path although it is a little less efficient per flop (penalties measured with gemm_bench).
-    static const int forced_tile = getenv("CSWIN_GEMM_TILE") ? atoi(getenv("CSWIN_GEMM_TILE")) : 0;  // tuning aid: 1 = 64x64, 2 = 64x32
+    const int forced_tile = cswin_tuning().gemm_tile;                                                // tuning aid: 1 = 64x64, 2 = 64x32
     // measured (profiles/round1_gemm_tiles.txt): a 64 x 32 tile costs ~1.2x per flop, so it only pays where it cuts the
     // critical CU's share by more than that (296 -> 592 tiles: 2 -> 1.5 units); 32 x 32 single-wave tiles never paid.
-    static const double pen2 = getenv("CSWIN_GEMM_PEN2") ? atof(getenv("CSWIN_GEMM_PEN2")) : 1.20;
+    const double pen2 = cswin_tuning().gemm_pen2;
     auto cost = [&](int bm, int bn, double pen) { return (double)((blocks(bm, bn) + 255) / 256) * bm * bn * pen; };
     int tile = 1;
     if (splits == 1 && cost(64, 32, pen2) < cost(64, 64, 1.0)) tile = 2;
@@ -653,7 +653,7 @@ void choose_split(int M, int out_rows, int out_cols, int* splits, int* r_per_spl
     // Every workgroup is resident at once and the kernel ends with the most loaded CU, so aim at a workgroup count
     // that is a whole multiple of the 256 CUs (3 per CU): slices need not be multiples of the k-tile (the loaders mask
     // the ragged last tile), only of 8.
-    static const int target_env = getenv("CSWIN_GEMM_SPLIT_WGS") ? atoi(getenv("CSWIN_GEMM_SPLIT_WGS")) : 768;   // tuning aid
+    const int target_env = cswin_tuning().gemm_split_wgs;                                                       // tuning aid
     const int target = target_override > 0 ? target_override : target_env;
     long tiles = (long)cdiv(out_rows, 64) * cdiv(out_cols, 64);
     int s = (int)(target / tiles);
@@ -890,7 +890,7 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
         }
         return CSWIN_OK;
     }
-    static const int w16_off = getenv("CSWIN_WGRAD16") ? atoi(getenv("CSWIN_WGRAD16")) == 0 : 0;     // tuning aid
+    const int w16_off = !cswin_tuning().wgrad16_on;                                                  // tuning aid
     if (precision == 1 && (!w16_off || d[0].io_bf16 || (n > 1 && d[1].io_bf16) || (n > 2 && d[2].io_bf16) || (n > 3 && d[3].io_bf16))) {
         // bf16 operands: 128 x 128 tiles, ~3 workgroups per CU over the whole batch (load-bound: see wgrad16.hip)
         // Workgroups are shared out in proportion to the work (rows x tiles), so that every workgroup of the launch walks the same
@@ -903,8 +903,7 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
             const int M = d[i].M, N = d[i].N, K = d[i].K;
             const long slab = ((long)N * K + N) * (long)sizeof(float);
             const int tiles = cdiv(N, 128) * cdiv(K, 128);
-            static const int w16_wgs = getenv("CSWIN_W16_WGS") ? atoi(getenv("CSWIN_W16_WGS")) : 768;      // tuning aid
-            static const int w16_even = getenv("CSWIN_W16_EVEN") ? atoi(getenv("CSWIN_W16_EVEN")) : 0;      // tuning aid: 1 = equal share per problem
+            const int w16_wgs = cswin_tuning().w16_wgs, w16_even = cswin_tuning().w16_even;                // tuning aids (1 = equal share per problem)
             int s = w16_even ? (w16_wgs / n) / tiles : (int)(w16_wgs * ((double)M * tiles / work_total) / tiles + 0.5);
             const int cap = (int)(d[i].ws_bytes / slab);
             if (s > cap) s = cap;
@@ -926,11 +925,11 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
         int splits, rps;
         // 1024 workgroups per launch, i.e. exactly 4 per CU, shared by the problems (measured with four problems: 192 / 256 /
         // 320 per problem -> 13.80 / 13.55 / 14.09 ms per step); a quarter of the slab traffic of four stand-alone launches
-        static const int batch_env = getenv("CSWIN_GEMM_BATCH_WGS") ? atoi(getenv("CSWIN_GEMM_BATCH_WGS")) : 0;   // tuning aid
+        const int batch_env = cswin_tuning().gemm_batch_wgs;                                                      // tuning aid
         // Equal shares per problem (the C x C problem then has 294-row workgroups beside the 1176-row ones of the C x 4C problems).
         // Shares in proportion to the work (CSWIN_GEMM_BATCH_EVEN=0), which pays for the load-bound bf16 kernel above, measured
         // SLOWER here: 13.70 against 13.28 ms/step -- this kernel is matrix-pipe bound and the extra slabs cost more than the tail.
-        static const int batch_even = getenv("CSWIN_GEMM_BATCH_EVEN") ? atoi(getenv("CSWIN_GEMM_BATCH_EVEN")) : 1;  // tuning aid
+        const int batch_even = cswin_tuning().gemm_batch_even;                                                      // tuning aid
         const int total_wgs = batch_env > 0 ? (batch_env < 1024 ? batch_env : 1024) * n : 1024;
         int batch_target = total_wgs / n;                                                            // the workspace query covers <= 1024
         if (!batch_even) {

@@ -252,13 +252,13 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512) void gemm16_kernel(G16Params
 template <int EPI, bool BT, bool PRE16>
 int g16_launch(const G16Params& p, hipStream_t st) {
     const int nsteps = (p.R + G16_T - 1) / G16_T;
-    static const int forced = getenv("CSWIN_GEMM16_STAGES") ? atoi(getenv("CSWIN_GEMM16_STAGES")) : 0;      // tuning aid: 2 .. 4
-    static const int forced_kg = getenv("CSWIN_GEMM16_KG") ? atoi(getenv("CSWIN_GEMM16_KG")) : 0;           // tuning aid: 1 / 2
+    const int forced = cswin_tuning().gemm16_stages;                                                        // tuning aid: 2 .. 4
+    const int forced_kg = cswin_tuning().gemm16_kg;                                                         // tuning aid: 1 / 2
     // Two k-groups for long reductions with about one workgroup per CU: stand-alone the workgroup life drops (K = 1024: 13.5 k ->
     // 11.3 k cycles, kernel span 10.0 -> 7.7 us), inside the step it does not pay (7.57 against 7.51 ms/step, twice each):
     // opt-in only (CSWIN_GEMM16_KG=2 applies it where nsteps >= 8 and nblk <= 400).
     const bool kg2 = forced_kg == 2 && nsteps >= 8 && nsteps % 2 == 0 && p.R % G16_T == 0 && p.nblk <= 400;
-    static const int forced_tm = getenv("CSWIN_GEMM16_TM") ? atoi(getenv("CSWIN_GEMM16_TM")) : 0;           // tuning aid: 64 / 128
+    const int forced_tm = cswin_tuning().gemm16_tm;                                                         // tuning aid: 64 / 128
     const bool tm128 = !kg2 && (forced_tm == 128 || (forced_tm == 0 && p.nblk > 768));
     int S = nsteps >= 3 ? 3 : 2;          // 48 KB: three workgroups per CU (measured against 2 and 4 stages: profiles/round2_notes.md)
     if (forced >= 2 && forced <= 4) S = forced;
@@ -298,7 +298,7 @@ int g16_launch(const G16Params& p, hipStream_t st) {
 // single-source forms).  mode 0: forward (A (M, R), B (NO, R));  mode 1: data gradient (A (M, R), B (R, NO)).
 // Returns 0 when launched, 1 when the shape is not covered (the caller falls back to the tiled family).
 int cswin_gemm16(int mode, int epi_mode, const void* A, const void* B, const void* epilogue, int M, int NO, int R, void* stream) {
-    static const bool off = getenv("CSWIN_GEMM16") && atoi(getenv("CSWIN_GEMM16")) == 0;                    // tuning aid
+    const bool off = !cswin_tuning().gemm16_on;                                                             // tuning aid
     if (off || (R % G16_T != 0 && R % G16_T != 32) || R < G16_T || NO % 8 != 0 || M < 1) return 1;    // reduction: n x 64 (+ 32)
     if ((((uintptr_t)A) | ((uintptr_t)B)) & 15) return 1;
     G16Params p;

@@ -412,7 +412,7 @@ int cswin_wgrad16_batch(const cswin_wgrad_desc* d, int n, const int* splits, con
         P.dy_bf16 = d[i].io_bf16 & 1;
         P.x_bf16 = (d[i].io_bf16 >> 1) & 1;
         P.slab_stride = (long)P.N * P.K + P.N;
-        static const bool dma_off = getenv("CSWIN_W16_DMA") && atoi(getenv("CSWIN_W16_DMA")) == 0;         // tuning aid
+        const bool dma_off = !cswin_tuning().w16_dma;                                                      // tuning aid
         P.dma = !dma_off && P.dy_bf16 && P.x_bf16 && P.M % W16_MS == 0 && P.rows_per_split % W16_MS == 0 &&
                 P.N % 8 == 0 && P.K % 8 == 0 && ((((uintptr_t)P.dy) | ((uintptr_t)P.x)) & 15) == 0 &&
                 (!P.row_scale || P.rows_per_split / P.rows_per_sample + 2 <= W16_SC_SAMPLES);

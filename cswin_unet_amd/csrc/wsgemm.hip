@@ -450,8 +450,8 @@ int ws_dispatch(const WsCfg& c, WsParams& p, hipStream_t st) {
 // mode: 0 = forward (W [N][R]), 1 = data gradient (W [R][N]).  epi_mode: EPI_PLAIN / EPI_ACT / EPI_RES / EPI_GELUBWD.
 static long long* g_ws_stamps = nullptr;
 extern "C" void cswin_debug_set_ws_stamps(void* p) { g_ws_stamps = (long long*)p; }
-static int g_ws_enabled = -1;       // debug / tuning aid only (cswin_debug_set_ws_gemm): A/B the two families in one process
-extern "C" void cswin_debug_set_ws_gemm(int on) { g_ws_enabled = on; }
+static int g_ws_override = -1;      // debug hook only (cswin_debug_set_ws_gemm, tools/ws_gemm_check.py): A/B the two families in one process
+extern "C" void cswin_debug_set_ws_gemm(int on) { g_ws_override = on; }
 
 int cswin_ws_gemm(int mode, int epi_mode, const float* A, const float* W, const void* epilogue, int M, int N, int R, void* stream) {
     // CSWIN_WS_GEMM / cswin_debug_set_ws_gemm: 0 (default) = never, 1 = wherever a layout exists (A/B runs), 2 = where the cost
@@ -459,18 +459,18 @@ int cswin_ws_gemm(int mode, int epi_mode, const float* A, const float* W, const 
     // which it measured faster than the tiled family stand-alone (profiles/round2_ws_gemm_vs_tiled.txt: -0.19 ms per step
     // picking the better of the two per shape).  Inside the training step that gain does not materialise (13.25 / 13.28 /
     // 13.46 ms per step for modes 0 / 2 / 1), so the default path stays the tiled family.
-    if (g_ws_enabled < 0) g_ws_enabled = getenv("CSWIN_WS_GEMM") ? atoi(getenv("CSWIN_WS_GEMM")) : 0;
-    if (!g_ws_enabled) return 1;
+    const int ws_mode = g_ws_override >= 0 ? g_ws_override : cswin_tuning().ws_gemm;
+    if (!ws_mode) return 1;
     if (M < 512 || N % 4 != 0 || R % 4 != 0 || !aligned16(A) || !aligned16(W)) return 1;
     WsCfg c;
     if (!ws_choose(M, N, R, epi_mode == EPI_RES || epi_mode == EPI_GELUBWD, &c)) return 1;
-    if (g_ws_enabled == 2) {
+    if (ws_mode == 2) {
         const double ideal = 2.0 * M * (double)N * R / (256.0 * 256.0);       // cycles at 64 flop / clk / SIMD on 256 CUs
         if (N < 128 || c.cost > 1.7 * ideal) return 1;
     }
-    if (const char* f = getenv("CSWIN_WS_LAYOUT")) {        // tuning aid: "nwn,nwk" forces a wave layout where it fits R
-        int a = 0, b = 0;
-        if (sscanf(f, "%d,%d", &a, &b) == 2 && b > 0 && R % b == 0) {
+    if (cswin_tuning().ws_nwk > 0) {                        // tuning aid CSWIN_WS_LAYOUT = "nwn,nwk": forces a wave layout where it fits R
+        const int a = cswin_tuning().ws_nwn, b = cswin_tuning().ws_nwk;
+        if (R % b == 0) {
             const int ks = R / b;
             if (ks == 64 || ks == 128 || ks == 192 || ks == 256) c = WsCfg{ks, a, b, 0.0};
             else return 1;
