@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64 * (QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8))) 
     (void)Q16; (void)Y16; (void)M16;
     constexpr int NP = 16 * NT;
     constexpr int NW = QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8);
-    static_assert(QS == 1 || NT <= 8, "query split only for windows of up to 128 tokens");
+    static_assert(QS == 1 || NT <= 18, "query split: one query tile per wave, at most 9 waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;                  // [NP][LDT]
     float* Vs = Ks + NP * LDT;         // [NP][LDT]
@@ -1219,13 +1219,18 @@ int launch_fwd_q(const AttnParams& p, int nwg, hipStream_t st) {
         // stream operation: it stays out of graph captures); the size is a constant of the template
         static std::once_flag once;
         static hipError_t status = hipSuccess;
-        std::call_once(once, [&] { status = hipFuncSetAttribute((const void*)attn_fwd_kernel<NT, 1, Q16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+        std::call_once(once, [&] {
+            status = hipFuncSetAttribute((const void*)attn_fwd_kernel<NT, 1, Q16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (status == hipSuccess) status = hipFuncSetAttribute((const void*)attn_fwd_kernel<NT, 2, Q16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        });
         if (status != hipSuccess) { cswin_set_error("attn_fwd: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(status)); return CSWIN_ERR_HIP; }
     }
-    if constexpr (NT <= 8) {
-        // few units relative to the 256 CUs: split the query tiles over two workgroups per unit (see the kernel)
+    {
+        // few units relative to the 256 CUs: split the query tiles over two workgroups per unit (see the kernel).  Large windows
+        // (NT > 8: 384 x 384 inputs, 128 units at batch 8) otherwise leave half the chip idle and give a wave 2 - 3 query tiles.
         const int force = cswin_tuning().attn_fwd_qsplit;                                // tuning aid: 1 or 2
-        const bool split = force ? force == 2 : (nwg < 1024 && nwg % 256 != 0 && NT >= 6);   // measured: pays at N = 98, not at N = 49
+        const bool split = force ? force == 2 : (NT <= 8 ? (nwg < 1024 && nwg % 256 != 0 && NT >= 6)   // measured: pays at N = 98, not at N = 49
+                                                         : nwg <= 256);
         if (split) {
             hipLaunchKernelGGL((attn_fwd_kernel<NT, 2, Q16>), dim3(2 * nwg), dim3(64 * ((NT + 1) / 2)), lds, st, p, nwg);
             return CSWIN_OK;
