@@ -82,6 +82,7 @@ def attention_roofline(batch, cfg, img_size=224, bf16=False):
         b = [(torch.randn(cb, generator=g) * 0.02).to(dev) for _ in idx]
         dy = torch.randn(batch, L, C, generator=g).to(dev)
         y = torch.empty(batch, L, C, device=dev, dtype=adt)
+        y0 = torch.empty_like(y)                                     # P V without the LePE term: written by the forward for the backward
         lse = torch.empty(batch, sum(hb), L, device=dev)
         dqkv = torch.empty_like(qkv)
         dw, db = [torch.empty_like(t) for t in w], [torch.empty_like(t) for t in b]
@@ -89,9 +90,9 @@ def attention_roofline(batch, cfg, img_size=224, bf16=False):
         pa = lambda ts: (ctypes.c_void_p * nb)(*[t.data_ptr() for t in ts])
         nbytes = lib().cswin_attn_bwd_workspace(batch, reso, C, nb, ha, ia, split[si])
         ws = torch.empty(nbytes // 4 + 4, device=dev)
-        t_f = _graph_time(lambda: call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(lse), batch, reso, C, nb, ha, ia,
+        t_f = _graph_time(lambda: call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(y0), ptr(lse), batch, reso, C, nb, ha, ia,
                                        split[si], 0.0, 0.0, 0, mode, stream()))
-        t_b = _graph_time(lambda: call("cswin_attn_bwd", ptr(qkv), pa(w), pa(b), ptr(lse), ptr(y), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws),
+        t_b = _graph_time(lambda: call("cswin_attn_bwd", ptr(qkv), pa(w), pa(b), ptr(lse), ptr(y0), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws),
                                        nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, None, 0.0, 0, mode, stream()))
         flops_f = 4.0 * L * n_tok * C * batch
         n_blocks = 2 * depth[si]

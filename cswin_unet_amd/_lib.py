@@ -20,7 +20,7 @@ SIGNATURES = {
     "cswin_last_error": (c_char_p, []),
     "cswin_abi_version": (I, []),
     "cswin_device_ok": (I, []),
-    "cswin_attn_fwd": (I, [P, P, P, P, P, I, I, I, I, P, P, I, F, F, ctypes.c_ulonglong, I, P]),
+    "cswin_attn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, P, P, I, F, F, ctypes.c_ulonglong, I, P]),
     "cswin_attn_bwd_workspace": (SZ, [I, I, I, I, P, P, I]),
     "cswin_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, I, I, P, P, I, F, P, F, ctypes.c_ulonglong, I, P]),
     "cswin_img2windows": (I, [P, P, I, I, I, I, I, I, P]),

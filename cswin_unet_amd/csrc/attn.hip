@@ -26,6 +26,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <mutex>
+#include <type_traits>
 
 namespace {
 
@@ -38,6 +39,7 @@ struct AttnBranch {
     int head0;       // global index of its first head (for the lse layout)
     int H_sp, W_sp, nW, nWin;
     int wg_begin;    // first workgroup of this branch
+    unsigned m_heads, m_nWin, m_nW, m_Wsp;   // ceil(2^32 / d) of the four divisors of the index arithmetic (fdiv below)
     const float* lepe_w;   // [Cb][9]
     const float* lepe_b;   // [Cb]
     float* dw_part;        // backward: partial slabs [b * nWin + win][Cb * 9 (channel-major, tap minor) | Cb] of the
@@ -47,9 +49,10 @@ struct AttnBranch {
 struct AttnParams {
     const float* qkv;      // (B, L, 3C)
     float* y;              // (B, L, C)        forward output
+    float* y0;             // (B, L, C)        forward output without the LePE term (P V), saved for the backward's delta; or NULL
     float* lse;            // (B, heads_total, L)
     const float* dy;       // (B, L, C)        backward input
-    const float* y_in;     // (B, L, C)        forward output (large-window backward only: delta = rowsum(dO o (y - lepe)))
+    const float* y_in;     // (B, L, C)        backward: the forward's y0 = P V (delta = rowsum(dO o y0) = rowsum(P o dP))
     float* delta;          // (B, heads_total, L) workspace (large-window backward only)
     float* dqkv;           // (B, L, 3C)       backward output
     int B, reso, C, heads_total;
@@ -61,6 +64,7 @@ struct AttnParams {
     int nbranch;
     int ds_stride;         // fused backward: LDS row stride of the dS image (>= N, = 4 mod 8: conflict-free column writes)
     int slab_rows;         // LePE gradient slab rows per window (1 on every current path)
+    int vs_floats;         // fused backward: floats of the V / dS region (see attn_bwd3_kernel)
     long long* stamps;     // debug (cswin_debug_set_attn_stamps): [workgroup][8] s_memtime stamps of wave 0, or NULL
     int qkv_bf16;          // storage mode: bit 0 = qkv and dqkv, bit 1 = y are STORED as bf16 (bf16 activation storage; 0, 1 or 3);
                            // all arithmetic stays fp32
@@ -99,6 +103,12 @@ struct WgInfo {
     int bi, b, win, g, N, ih, iw;
 };
 
+// n / d for 0 <= n < 2^20 and 0 < d < 2^12 by one multiply-high with m = ceil(2^32 / d) (the integer division the compiler
+// emits is ~35 VALU instructions; the index arithmetic of a unit has eight of them and these kernels are issue-bound outside
+// their MFMA loops)
+__device__ __forceinline__ int fdiv(int n, unsigned m) { return (int)__umulhi((unsigned)n, m); }
+static inline unsigned fdiv_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+
 // nn.Dropout on the attention probabilities (cswin_unet.py:101, attn_drop_rate > 0; no reference config uses it): the keep factor
 // (0 or 1 / (1 - p)) of probability (query tq, key tk) of (batch, head, window) unit `uid` is a counter-based hash of
 // (seed, element index), so the backward kernels regenerate the forward's mask instead of storing an N x N tensor per head.
@@ -119,16 +129,30 @@ __device__ __forceinline__ float attn_keep(const AttnParams& p, long uid, int N,
     return (unsigned)(r >> 40) >= p.drop_thresh ? p.drop_scale : 0.f;
 }
 
+// the keep decisions of NB (query, key) pairs as ONE bit mask, built by a rolled loop: unrolled, the 64-bit hashes of a whole tile
+// row interleave and cost the persistent kernels 100 VGPRs (spills) for a path no reference configuration enables
+template <int NB, typename F>
+__device__ __forceinline__ unsigned attn_keep_bits(const AttnParams& p, long uid, int N, F&& qk) {
+    unsigned bits = 0;
+#pragma unroll 1
+    for (int i = 0; i < NB; ++i) {
+        int tq, tk;
+        qk(i, tq, tk);
+        bits |= (attn_keep(p, uid, N, tq, tk) != 0.f ? 1u : 0u) << i;
+    }
+    return bits;
+}
+
 __device__ __forceinline__ WgInfo decode_wg(const AttnParams& p, int wg) {
     WgInfo w;
     w.bi = (p.nbranch > 1 && wg >= p.br[1].wg_begin) ? 1 : 0;
     const AttnBranch& br = p.br[w.bi];
-    int loc = wg - br.wg_begin;
-    w.g = loc % br.heads;
-    int t = loc / br.heads;
-    w.win = t % br.nWin;
-    w.b = t / br.nWin;
-    w.ih = w.win / br.nW;
+    const int loc = wg - br.wg_begin;
+    const int t = br.heads > 1 ? fdiv(loc, br.m_heads) : loc;
+    w.g = loc - t * br.heads;
+    w.b = br.nWin > 1 ? fdiv(t, br.m_nWin) : t;
+    w.win = t - w.b * br.nWin;
+    w.ih = br.nW > 1 ? fdiv(w.win, br.m_nW) : w.win;
     w.iw = w.win - w.ih * br.nW;
     w.N = br.H_sp * br.W_sp;
     return w;
@@ -136,7 +160,7 @@ __device__ __forceinline__ WgInfo decode_wg(const AttnParams& p, int wg) {
 
 // in-window token t -> image token l
 __device__ __forceinline__ int token_of(const AttnBranch& br, const WgInfo& w, int reso, int t) {
-    int r = t / br.W_sp, c = t - r * br.W_sp;
+    const int r = br.W_sp > 1 ? fdiv(t, br.m_Wsp) : t, c = t - r * br.W_sp;
     return (w.ih * br.H_sp + r) * reso + w.iw * br.W_sp + c;
 }
 
@@ -395,23 +419,250 @@ __global__ __launch_bounds__(64 * (QS == 2 ? (NT + 1) / 2 : (NT < 8 ? NT : 8))) 
         // lane now holds O^T[d = 16 df + 4 kq + e][q = li]
         if (qt == qt0) ATTN_STAMP(3);
         if (qvalid) {
-            const int rr = thin ? 0 : tq / br.W_sp, cc = thin ? 0 : tq - rr * br.W_sp;      // thin stripes: unused
+            const int rr = thin ? 0 : fdiv(tq, br.m_Wsp), cc = thin ? 0 : tq - rr * br.W_sp;      // thin stripes: unused
 #pragma unroll
             for (int df = 0; df < 2; ++df) {
                 const int d0 = 16 * df + 4 * kq;
                 f32x4 acc = *reinterpret_cast<const f32x4*>(&Wl[9 * HD + d0]);     // bias
                 acc = thin ? lepe_taps4<true, 1>(br, Vs, Wl, rr, cc, tq, d0, acc) : lepe_taps4<false, 1>(br, Vs, Wl, rr, cc, tq, d0, acc);
-                f32x4 out = o[df] * inv + acc;
+                const f32x4 out0 = o[df] * inv, out = out0 + acc;
                 if (d0 < p.hd) {
                     const long yi = ((long)w.b * L + lq) * p.C + ch0 + d0;
                     if constexpr (Y16) *reinterpret_cast<attn_bf16x4*>(reinterpret_cast<__bf16*>(p.y) + yi) = __builtin_convertvector(out, attn_bf16x4);
                     else *reinterpret_cast<f32x4*>(p.y + yi) = out;
+                    if (p.y0) {
+                        if constexpr (Y16) *reinterpret_cast<attn_bf16x4*>(reinterpret_cast<__bf16*>(p.y0) + yi) = __builtin_convertvector(out0, attn_bf16x4);
+                        else *reinterpret_cast<f32x4*>(p.y0 + yi) = out0;
+                    }
                 }
             }
             if (kq == 0) p.lse[((long)w.b * p.heads_total + br.head0 + w.g) * L + lq] = mx + __logf(sum);
         }
     }
     ATTN_STAMP(4);
+}
+
+// =====================================================================================
+// forward, windows of up to 128 tokens
+// =====================================================================================
+// An ITEM is one (branch, window, head) unit (QS = 1) or one half of its query tiles (QS = 2: `units` apart in the grid, i.e.
+// on the same XCD when units is a multiple of 8); one workgroup per item, one query tile per wave.  All q / k / v loads are
+// issued first; the K stripe goes to LDS at once, the V stripe only after the S / softmax phase, so that its load latency hides
+// behind that phase.  (Round 3 also built persistent workgroups that prefetch their next item into registers while computing
+// the current one: with 2 - 3 resident workgroups per CU instead of 4 - 6 and ~40 more live registers it was 5 - 8 % slower on
+// every stage than one workgroup per item, whose neighbours on the CU hide the same latencies; profiles/round3_notes.md.)
+__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
+
+template <int NT, int QS, int ST>
+__global__ __launch_bounds__(64 * (QS == 2 ? (NT + 1) / 2 : NT), 4) void attn_fwd3_kernel(AttnParams p, int units) {
+    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0, M16 = (ST & 4) != 0;
+    (void)Q16; (void)Y16; (void)M16;
+    static_assert(NT <= 8, "one query tile per wave");
+    constexpr int NP = 16 * NT;
+    constexpr int NW = QS == 2 ? (NT + 1) / 2 : NT;
+    constexpr int T = 64 * NW;
+    constexpr int NLD = (NP * 8 + T - 1) / T;          // 16-B row chunks of K (and of V) staged per thread
+    static_assert(10 * HD <= 2 * T, "LePE taps: at most two per thread");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                  // [NP][LDT]
+    float* Vs = Ks + NP * LDT;         // [NP][LDT]
+    float* Wl = Vs + NP * LDT;         // [10][32]: 9 taps + bias of this head's channels
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int L = p.reso * p.reso, C3 = 3 * p.C;
+    typedef typename QRaw<Q16>::type raw_t;
+
+    // registers of the item being fetched
+    raw_t kraw[NLD], vraw[NLD], q0r = {}, q1r = {};
+    float wl0 = 0.f, wl1 = 0.f;
+    int lq_r = 0;
+    auto item_info = [&](int item, int& half) {
+        half = QS == 2 ? item / units : 0;
+        return decode_wg(p, QS == 2 ? item - half * units : item);
+    };
+    auto issue_kq = [&](int item) {
+        int half;
+        const WgInfo w = item_info(item, half);
+        const AttnBranch& br = p.br[w.bi];
+        const int ch0 = br.c0 + w.g * p.hd, N = w.N;
+        const float* qkv_b = p.qkv + (long)w.b * L * C3;
+        const int qt0 = half * NW + wave, tq = 16 * qt0 + li;
+        q0r = {};
+        q1r = {};
+        lq_r = 0;
+        if (qt0 < NT && tq < N) lq_r = token_of(br, w, p.reso, tq);
+        if (qt0 < NT && tq < N && 8 * kq < p.hd) {
+            const float* src = qkv_b + (long)lq_r * C3 + ch0 + 8 * kq;
+            q0r = ldq_raw<Q16>(p, src);
+            q1r = ldq_raw<Q16>(p, src + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * T, row = idx >> 3, c4 = idx & 7;
+            kraw[i] = {};
+            if (idx < NP * 8 && row < N && 4 * c4 < p.hd)
+                kraw[i] = ldq_raw<Q16>(p, qkv_b + (long)token_of(br, w, p.reso, row) * C3 + ch0 + 4 * c4 + p.C);
+        }
+        {
+            const int tap = tid / HD, ch = tid - tap * HD, cb = ch0 - br.c0 + ch;
+            wl0 = (tid >= 10 * HD || ch >= p.hd) ? 0.f : (tap < 9 ? br.lepe_w[cb * 9 + tap] : br.lepe_b[cb]);
+            const int i2 = tid + T, tap2 = i2 / HD, ch2 = i2 - tap2 * HD, cb2 = ch0 - br.c0 + ch2;
+            wl1 = (i2 >= 10 * HD || ch2 >= p.hd) ? 0.f : (tap2 < 9 ? br.lepe_w[cb2 * 9 + tap2] : br.lepe_b[cb2]);
+        }
+    };
+    auto issue_v = [&](int item) {
+        int half;
+        const WgInfo w = item_info(item, half);
+        const AttnBranch& br = p.br[w.bi];
+        const int ch0 = br.c0 + w.g * p.hd, N = w.N;
+        const float* qkv_b = p.qkv + (long)w.b * L * C3;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * T, row = idx >> 3, c4 = idx & 7;
+            vraw[i] = {};
+            if (idx < NP * 8 && row < N && 4 * c4 < p.hd)
+                vraw[i] = ldq_raw<Q16>(p, qkv_b + (long)token_of(br, w, p.reso, row) * C3 + ch0 + 4 * c4 + 2 * p.C);
+        }
+    };
+
+    const int item = blockIdx.x;
+    ATTN_STAMP(0);
+    issue_kq(item);
+    issue_v(item);
+    {
+        int half;
+        const WgInfo w = item_info(item, half);
+        const AttnBranch& br = p.br[w.bi];
+        const int ch0 = br.c0 + w.g * p.hd, N = w.N;
+        const bool thin = br.H_sp == 1 || br.W_sp == 1;       // wave-uniform
+        const int qt = half * NW + wave;                      // this wave's query tile
+        const int tq = 16 * qt + li;
+        const bool qvalid = qt < NT && tq < N;
+        const int lq = lq_r;
+
+        // ---- K stripe, LePE taps -> LDS; this wave's Q fragment ----
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * T, row = idx >> 3, c4 = idx & 7;
+            if (idx < NP * 8) *reinterpret_cast<f32x4*>(&Ks[row * LDT + 4 * c4]) = qcv(kraw[i]);
+        }
+        if (tid < 10 * HD) Wl[tid] = wl0;
+        if (tid + T < 10 * HD) Wl[tid + T] = wl1;
+        float qr[8];
+        {
+            const f32x4 q0 = qcv(q0r), q1 = qcv(q1r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                qr[e] = q0[e] * p.scale;
+                qr[4 + e] = q1[e] * p.scale;
+            }
+        }
+        lds_barrier();
+        ATTN_STAMP(1);
+
+        // ---- S^T tiles: rows = keys (16 kt + 4 kq + reg), col = query li; softmax over registers + two shuffles ----
+        f32x4 s[NT];
+        float mx = -INFINITY, sum = 0.f;
+        if (qt < NT) {
+            const attn_bf16x8 qb = pk8(f32x4{qr[0], qr[1], qr[2], qr[3]}, f32x4{qr[4], qr[5], qr[6], qr[7]});     // M16 only
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const float* kp = &Ks[(16 * kt + li) * LDT + 8 * kq];
+                const f32x4 k0 = *reinterpret_cast<const f32x4*>(kp);
+                const f32x4 k1 = *reinterpret_cast<const f32x4*>(kp + 4);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (M16) {
+                    acc = mfma32(pk8(k0, k1), qb, acc);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = mfma4(k0[e], qr[e], acc);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = mfma4(k1[e], qr[4 + e], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (16 * kt + 4 * kq + r >= N) acc[r] = -INFINITY;
+                    mx = fmaxf(mx, acc[r]);
+                }
+                s[kt] = acc;
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(s[kt][r] - mx);
+                    s[kt][r] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            if (p.drop_p > 0.f) {                      // attention dropout: P o M goes into P V, the statistics stay those of P
+                const unsigned keep = attn_keep_bits<4 * NT>(p, attn_unit_id(p, br, w.b, w.g, w.win), N,
+                                                             [&](int i, int& q_, int& k_) { q_ = tq; k_ = 16 * (i >> 2) + 4 * kq + (i & 3); });
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[kt][r] *= (keep >> (4 * kt + r)) & 1u ? p.drop_scale : 0.f;
+            }
+        }
+        ATTN_STAMP(2);
+
+        // ---- V stripe -> LDS ----
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * T, row = idx >> 3, c4 = idx & 7;
+            if (idx < NP * 8) *reinterpret_cast<f32x4*>(&Vs[row * LDT + 4 * c4]) = qcv(vraw[i]);
+        }
+        lds_barrier();
+
+        // ---- O^T[d][q] = sum_key V[key][d] * P^T[key][q]; the P accumulator tile is the B operand as it stands ----
+        if (qt < NT) {
+            const float inv = 1.0f / sum;
+            f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                if constexpr (M16) {
+                    const float* vp = &Vs[(16 * kt + 4 * kq) * LDT + li];
+                    const attn_s16x4 pb = pk4(s[kt]);
+                    o[0] = mfma16(pk4(f32x4{vp[0], vp[LDT], vp[2 * LDT], vp[3 * LDT]}), pb, o[0]);
+                    o[1] = mfma16(pk4(f32x4{vp[16], vp[LDT + 16], vp[2 * LDT + 16], vp[3 * LDT + 16]}), pb, o[1]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float* vp = &Vs[(16 * kt + 4 * kq + r) * LDT + li];
+                        o[0] = mfma4(vp[0], s[kt][r], o[0]);
+                        o[1] = mfma4(vp[16], s[kt][r], o[1]);
+                    }
+                }
+            }
+            ATTN_STAMP(3);
+            // lane holds O^T[d = 16 df + 4 kq + e][q = li]: LePE from the V image, scatter to (B, L, C)
+            if (qvalid) {
+                const int rr = thin ? 0 : fdiv(tq, br.m_Wsp), cc = thin ? 0 : tq - rr * br.W_sp;      // thin stripes: unused
+#pragma unroll
+                for (int df = 0; df < 2; ++df) {
+                    const int d0 = 16 * df + 4 * kq;
+                    f32x4 acc = *reinterpret_cast<const f32x4*>(&Wl[9 * HD + d0]);     // bias
+                    acc = thin ? lepe_taps4<true, 1>(br, Vs, Wl, rr, cc, tq, d0, acc) : lepe_taps4<false, 1>(br, Vs, Wl, rr, cc, tq, d0, acc);
+                    const f32x4 out0 = o[df] * inv, out = out0 + acc;
+                    if (d0 < p.hd) {
+                        const long yi = ((long)w.b * L + lq) * p.C + ch0 + d0;
+                        if constexpr (Y16) *reinterpret_cast<attn_bf16x4*>(reinterpret_cast<__bf16*>(p.y) + yi) = __builtin_convertvector(out, attn_bf16x4);
+                        else *reinterpret_cast<f32x4*>(p.y + yi) = out;
+                        if (p.y0) {
+                            if constexpr (Y16) *reinterpret_cast<attn_bf16x4*>(reinterpret_cast<__bf16*>(p.y0) + yi) = __builtin_convertvector(out0, attn_bf16x4);
+                            else *reinterpret_cast<f32x4*>(p.y0 + yi) = out0;
+                        }
+                    }
+                }
+                if (kq == 0) p.lse[((long)w.b * p.heads_total + br.head0 + w.g) * L + lq] = mx + __logf(sum);
+            }
+        }
+        ATTN_STAMP(4);
+    }
 }
 
 // =====================================================================================
@@ -425,345 +676,425 @@ __device__ __forceinline__ float oct_sum(float v) {
     return v;
 }
 
-// Fused backward, windows of up to 112 tokens.  LDS: QK [NP][LDT] (Q, later K) | Ds [NP][LDT] (dO) | VS (V, later the
-// dS image [NP][ds_stride]) | lse, delta [NP] | LePE taps + bias [10][HD]: 79 KB for N = 98, two workgroups per CU.
-//   P0  q, v, dO -> LDS; the K / V fragments of this wave's 16 keys and the y chunks stay in registers
-//   P1  delta[q] = sum_d dO (y - LePE(v) - bias)  (= rowsum(P o dP), so P and dP never have to be held for a second pass);
-//       LePE weight / bias gradient partial of this wave (kept in registers; combined over the waves at the very end)
-//   P2  per query tile: S, dP (MFMA) -> P, dS (VALU) -> dV^T += dO^T P, dK^T += Q^T dS (MFMA, the P / dS accumulator tiles
-//       are the B operands as they stand); dS -> LDS.  The S / dP products of tile qt + 1 are issued before the VALU
-//       work of tile qt.  Then dV += LePE^T(dO), dK, dV -> global.
-//   P3  K fragments -> LDS over the dead Q image; dQ^T = K^T dS^T per query tile (one per wave) -> global.
+// v[lane] + v[lane ^ 16] and v[lane] + v[lane ^ 32] by the gfx950 row / half swaps: VALU only (a __shfl_xor is a ds_bpermute round trip)
+__device__ __forceinline__ float xor16_sum(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
+// sum over the 16 lanes of a DPP row (the lanes that share lane >> 4): pure VALU, every lane gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+    v = oct_sum(v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));  // row_mirror
+    return v;
+}
+
+// Fused backward, windows of up to 112 tokens: one workgroup per (branch, window, head) unit.
+// LDS: QK [NP][LDT] (Q, later K) | Ds [NP][LDT] (dO) | VS (V, later the dS image [N][ds_stride] + pad) | lse, delta [NP] |
+// LePE taps + bias [10][HD]: 73 KB for N = 98, two workgroups per CU.  Wave w owns the 16 keys of key tile w.  Per item:
+//   A  q, v, dO, y0, lse, taps: global -> registers -> LDS; delta[q] = sum_d dO[q][d] y0[q][d] (= rowsum(P o dP): y0 = P V is the forward's
+//      output WITHOUT the LePE term, saved by the forward for exactly this) from the registers being staged, an 8-lane DPP sum
+//      per token; K / V fragments of the wave's keys -> registers; barrier
+//   B  LePE conv weight / bias gradient: wave w takes taps w, w + NT, ...; a lane = (token slice, 16-B channel chunk), the eight
+//      slices meet by DPP / shuffles, lanes 0-7 store the (window, head) partial -- no LDS scratch, no barrier
+//   C  barrier (V image dead); per query tile: S, dP (MFMA) -> P, dS (VALU) -> dV^T += dO^T P, dK^T += Q^T dS (MFMA, the P / dS
+//      accumulator tiles are the B operands as they stand); dS -> LDS over the V image.  The S / dP products of tile qt + 1 are
+//      issued before the VALU work of tile qt.  Then dV += LePE^T(dO); dK, dV -> global
+//   D  barrier; K fragments -> LDS over the dead Q image; barrier; dQ^T = K^T dS^T per query tile (one per wave) -> global
 template <int NT, int ST>
-__global__ __launch_bounds__(64 * NT, 4) void attn_bwd2_kernel(AttnParams p) {      // 4 waves per SIMD: <= 128 VGPRs, two workgroups per CU at NT = 7
-    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0, M16 = (ST & 4) != 0;      // storage of qkv / dqkv and of y, bf16 MFMAs (see AttnParams)
+__global__ __launch_bounds__(64 * NT, 4) void attn_bwd3_kernel(AttnParams p) {
+    constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0, M16 = (ST & 4) != 0;
     (void)Q16; (void)Y16; (void)M16;
     constexpr int NP = 16 * NT;
-    constexpr int NTHREADS = 64 * NT;
+    constexpr int T = 64 * NT;                 // NP * 8 = 2 T: two 16-B row chunks of each image per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int S = p.ds_stride;
     float* QK = smem;                       // [NP][LDT]
     float* Ds = QK + NP * LDT;              // [NP][LDT]
-    float* VS = Ds + NP * LDT;              // V [NP][LDT], then dS [NP][S]
-    constexpr int VS_MIN = NP * LDT + NT * 10 * HD;   // V image + the waves' LePE gradient slabs (P1)
-    float* lse_s = VS + (NP * S > VS_MIN ? NP * S : VS_MIN);
+    float* VS = Ds + NP * LDT;              // V [NP][LDT], then dS [N][S] (+ NP finite floats that row N - 1's tail reads)
+    float* lse_s = VS + p.vs_floats;
     float* del_s = lse_s + NP;
     float* Wl = del_s + NP;                 // [10][HD]
+    float* Gl = Wl + 10 * HD;               // [9 + NT][HD]: LePE weight gradient of this unit (taps by the waves that own them), per-wave bias gradients
 
-    const WgInfo w = decode_wg(p, blockIdx.x);
-    const AttnBranch& br = p.br[w.bi];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int L = p.reso * p.reso, C3 = 3 * p.C;
-    const int ch0 = br.c0 + w.g * p.hd;
-    const int N = w.N;
-    const float* qkv_b = p.qkv + (long)w.b * L * C3;
-    const float* dy_b = p.dy + (long)w.b * L * p.C;
-    const float* y_b = p.y_in + (long)w.b * L * p.C;
-    float* dqkv_b = p.dqkv + (long)w.b * L * C3;
-    const float* lse_b = p.lse + ((long)w.b * p.heads_total + br.head0 + w.g) * L;
-    const bool thin = br.H_sp == 1 || br.W_sp == 1;       // wave-uniform
+    typedef typename QRaw<Q16>::type raw_t;
+    typedef typename QRaw<Y16>::type rawy_t;
 
-    ATTN_STAMP(0);
-    // ---- P0: all global loads first, then the LDS stores ----
-    const int kw = wave;                               // key tile owned by this wave
-    const int tk = 16 * kw + li;                       // this lane's key token
-    const bool kvalid = tk < N;
-    const int lk = kvalid ? token_of(br, w, p.reso, tk) : 0;
-    typename QRaw<Q16>::type qv[2], vv[2];
+    const int item = blockIdx.x;
+    // the tail behind the dS image is only ever read (by padded query rows, against zero K rows): make it finite once
+    for (int i = tid; i < NP; i += T) VS[p.vs_floats - NP + i] = 0.f;
+
+    // registers of the item being fetched
+    raw_t qv[2], vv[2], k0r = {}, k1r = {};
+    rawy_t yv[2];
     f32x4 dv[2];
+    int bbits[2];              // border bits of the staged rows: 1 = row >= 1, 2 = row <= H_sp - 2, 4 = col >= 1, 8 = col <= W_sp - 2 (0: no token)
+    float lsev = 0.f, wl0 = 0.f, wl1 = 0.f;
+    auto issue = [&](int it_) {
+        const WgInfo w = decode_wg(p, it_);
+        const AttnBranch& br = p.br[w.bi];
+        const int ch0 = br.c0 + w.g * p.hd, N = w.N;
+        const float* qkv_b = p.qkv + (long)w.b * L * C3;
+        const float* dy_b = p.dy + (long)w.b * L * p.C;
+        const float* y_b = p.y_in + (long)w.b * L * p.C;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int idx = tid + it * NTHREADS, row = idx >> 3, c4 = idx & 7;
-        qv[it] = {};
-        vv[it] = {};
-        dv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (row < N && 4 * c4 < p.hd) {
-            const int l = token_of(br, w, p.reso, row);
-            const float* src = qkv_b + (long)l * C3 + ch0 + 4 * c4;
-            qv[it] = ldq_raw<Q16>(p, src);
-            vv[it] = ldq_raw<Q16>(p, src + 2 * p.C);
-            dv[it] = *reinterpret_cast<const f32x4*>(dy_b + (long)l * p.C + ch0 + 4 * c4);
-        }
-    }
-    // P1 walks tokens t = 8 wave + (lane >> 3) + 8 NT j, j = 0, 1 (eight lanes per token, lane & 7 = 16-B channel chunk): its
-    // y values, loaded now
-    const int pc4 = lane & 7, ptg = lane >> 3;
-    typename QRaw<Y16>::type yv[2];               // raw: widened where P1 consumes it
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int t = 8 * wave + ptg + 8 * NT * j;
-        yv[j] = {};
-        if (t < N && 4 * pc4 < p.hd) yv[j] = ldy_raw<Y16>(p, y_b + (long)token_of(br, w, p.reso, t) * p.C + ch0 + 4 * pc4);
-    }
-    for (int t = tid; t < NP; t += NTHREADS) {
-        lse_s[t] = t < N ? lse_b[token_of(br, w, p.reso, t)] : INFINITY;   // +inf -> P = 0 on padded query rows
-        del_s[t] = 0.f;
-    }
-    for (int i = tid; i < 10 * HD; i += NTHREADS) {
-        const int tap = i / HD, ch = i - tap * HD;
-        const int cb = ch0 - br.c0 + ch;
-        Wl[i] = ch >= p.hd ? 0.f : (tap < 9 ? br.lepe_w[cb * 9 + tap] : br.lepe_b[cb]);
-    }
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int idx = tid + it * NTHREADS, row = idx >> 3, c4 = idx & 7;
-        *reinterpret_cast<f32x4*>(&QK[row * LDT + 4 * c4]) = qcv(qv[it]);
-        *reinterpret_cast<f32x4*>(&VS[row * LDT + 4 * c4]) = qcv(vv[it]);
-        *reinterpret_cast<f32x4*>(&Ds[row * LDT + 4 * c4]) = dv[it];
-    }
-    __syncthreads();
-    ATTN_STAMP(1);
-
-    // ---- P1: per token: LePE weight-gradient terms, and delta = sum_d dO (y - bias - sum_tap W V_nbr) ----
-    // Eight lanes per token, four channels per lane: neighbour index and validity are computed once per 16 B instead of
-    // once per float, the taps are b128 LDS reads, delta is an 8-lane DPP sum.  The wave's [10][32] gradient partial goes
-    // to the part of the VS region that the V image does not use; it is combined over the waves after the barrier.
-    float* slab = VS + NP * LDT;                        // [NT][10][HD]
-    {
-        f32x4 a4[10];
-#pragma unroll
-        for (int i = 0; i < 10; ++i) a4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const f32x4 bias4 = *reinterpret_cast<const f32x4*>(&Wl[9 * HD + 4 * pc4]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int t = 8 * wave + ptg + 8 * NT * j;
-            const bool tv = t < N;
-            const int tc = tv ? t : 0;
-            f32x4 g4 = *reinterpret_cast<const f32x4*>(&Ds[tc * LDT + 4 * pc4]);
-            if (!tv) g4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            f32x4 lw4 = {0.f, 0.f, 0.f, 0.f};           // sum_tap W[tap] o V[nbr]
-            if (thin) {
-                const bool row = br.H_sp == 1;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {           // a4[q] holds tap (1, q) or (q, 1); expanded below
-                    const int t2 = tc + q - 1;
-                    const bool ok = (unsigned)t2 < (unsigned)N;
-                    f32x4 v4 = *reinterpret_cast<const f32x4*>(&VS[(ok ? t2 : tc) * LDT + 4 * pc4]);
-                    if (!ok) v4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&Wl[(row ? 3 + q : 3 * q + 1) * HD + 4 * pc4]);
-                    a4[q] += g4 * v4;
-                    lw4 += w4 * v4;
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + it * T, row = idx >> 3, c4 = idx & 7;
+            qv[it] = {};
+            vv[it] = {};
+            yv[it] = {};
+            dv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bbits[it] = 0;
+            if (row < N) {
+                const int r = br.W_sp > 1 ? fdiv(row, br.m_Wsp) : row, c = row - r * br.W_sp;
+                bbits[it] = (r >= 1 ? 1 : 0) | (r <= br.H_sp - 2 ? 2 : 0) | (c >= 1 ? 4 : 0) | (c <= br.W_sp - 2 ? 8 : 0) | 16;
+                if (4 * c4 < p.hd) {
+                    const int l = (w.ih * br.H_sp + r) * p.reso + w.iw * br.W_sp + c;
+                    const float* src = qkv_b + (long)l * C3 + ch0 + 4 * c4;
+                    qv[it] = ldq_raw<Q16>(p, src);
+                    vv[it] = ldq_raw<Q16>(p, src + 2 * p.C);
+                    dv[it] = *reinterpret_cast<const f32x4*>(dy_b + (long)l * p.C + ch0 + 4 * c4);
+                    yv[it] = ldy_raw<Y16>(p, y_b + (long)l * p.C + ch0 + 4 * c4);
                 }
-            } else {
-                const int rr = tc / br.W_sp, cc = tc - rr * br.W_sp;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int r2 = rr + ky - 1, c2 = cc + kx - 1;
-                        const bool ok = (unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp;
-                        f32x4 v4 = *reinterpret_cast<const f32x4*>(&VS[(ok ? r2 * br.W_sp + c2 : tc) * LDT + 4 * pc4]);
-                        if (!ok) v4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(&Wl[(ky * 3 + kx) * HD + 4 * pc4]);
-                        a4[ky * 3 + kx] += g4 * v4;
-                        lw4 += w4 * v4;
-                    }
             }
-            a4[9] += g4;
-            const f32x4 o4 = qcv(yv[j]) - bias4 - lw4;
-            const float part = oct_sum(g4[0] * o4[0] + g4[1] * o4[1] + g4[2] * o4[2] + g4[3] * o4[3]);
-            if (tv && pc4 == 0) del_s[t] = part;
         }
-        if (thin) {                                             // a4[0..2] -> taps (1, q) or (q, 1); the other six are zero
-            const bool row = br.H_sp == 1;
-            const f32x4 t0 = a4[0], t1 = a4[1], t2 = a4[2], zero = {0.f, 0.f, 0.f, 0.f};
-            a4[0] = a4[2] = a4[6] = a4[8] = zero;
-            a4[1] = row ? zero : t0;
-            a4[3] = row ? t0 : zero;
-            a4[4] = t1;
-            a4[5] = row ? t2 : zero;
-            a4[7] = row ? zero : t2;
-        }
-        // sum over the eight token slots of the wave (lanes that share lane & 7): rotate by 8 inside the DPP row, then
-        // across the four rows
-#pragma unroll
-        for (int i = 0; i < 10; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = a4[i][e];
-                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                a4[i][e] = v;
-            }
-        if (lane < 8) {
-#pragma unroll
-            for (int i = 0; i < 10; ++i) *reinterpret_cast<f32x4*>(&slab[(wave * 10 + i) * HD + 4 * lane]) = a4[i];
-        }
-    }
-    // K / V fragments of this wave's 16 keys (B operands of P2): fetched only now, so that they do not sit in registers
-    // through P1 (whose accumulators would otherwise spill); the K load's latency hides behind the two barriers below
-    float kf[8], vf[8];
-    {
-        typename QRaw<Q16>::type k0r = {}, k1r = {};
-        if (kvalid && 8 * kq < p.hd) {
-            const float* src = qkv_b + (long)lk * C3 + p.C + ch0 + 8 * kq;
+        k0r = {};
+        k1r = {};
+        const int tk = 16 * wave + li;
+        if (tk < N && 8 * kq < p.hd) {
+            const float* src = qkv_b + (long)token_of(br, w, p.reso, tk) * C3 + p.C + ch0 + 8 * kq;
             k0r = ldq_raw<Q16>(p, src);
             k1r = ldq_raw<Q16>(p, src + 4);
         }
-        const float* vp = &VS[tk * LDT + 8 * kq];
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp), v1 = *reinterpret_cast<const f32x4*>(vp + 4);
-        const f32x4 k0 = qcv(k0r), k1 = qcv(k1r);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            kf[e] = k0[e];
-            kf[4 + e] = k1[e];
-            vf[e] = v0[e];
-            vf[4 + e] = v1[e];
-        }
-    }
-    ATTN_STAMP(2);
-    __syncthreads();                                    // V image dead; delta and the waves' LePE partials complete
-    float lepe_part[2] = {0.f, 0.f};                    // elements tid, tid + NTHREADS of the workgroup's [10][HD] partial
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int i = tid + u * NTHREADS;
-        if (i < 10 * HD) {
-#pragma unroll
-            for (int k = 0; k < NT; ++k) lepe_part[u] += slab[k * 10 * HD + i];
-        }
-    }
-    __syncthreads();                                    // VS becomes the dS image
-
-    // ---- P2: fused S / dP -> P, dS -> dV^T, dK^T ----
-    f32x4 dVt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    f32x4 dKt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    const bool colok = 16 * kw + li < S;               // dS columns beyond the stride would land in the next row
-    const attn_bf16x8 kb = pk8(f32x4{kf[0], kf[1], kf[2], kf[3]}, f32x4{kf[4], kf[5], kf[6], kf[7]});       // M16 only
-    const attn_bf16x8 vb = pk8(f32x4{vf[0], vf[1], vf[2], vf[3]}, f32x4{vf[4], vf[5], vf[6], vf[7]});
-    auto s_dp = [&](int qt, f32x4& sa, f32x4& da) {
-        const float* qp = &QK[(16 * qt + li) * LDT + 8 * kq];
-        const float* dp = &Ds[(16 * qt + li) * LDT + 8 * kq];
-        const f32x4 q0 = *reinterpret_cast<const f32x4*>(qp), q1 = *reinterpret_cast<const f32x4*>(qp + 4);
-        const f32x4 d0 = *reinterpret_cast<const f32x4*>(dp), d1 = *reinterpret_cast<const f32x4*>(dp + 4);
-        sa = da = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (M16) {
-            sa = mfma32(pk8(q0, q1), kb, sa);
-            da = mfma32(pk8(d0, d1), vb, da);
-            return;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            sa = mfma4(q0[e], kf[e], sa);               // S[q][key] = sum_d Q[q][d] K[key][d]
-            da = mfma4(d0[e], vf[e], da);               // dP[q][key] = sum_d dO[q][d] V[key][d]
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            sa = mfma4(q1[e], kf[4 + e], sa);
-            da = mfma4(d1[e], vf[4 + e], da);
+        lsev = INFINITY;                                     // +inf -> P = 0 on padded query rows
+        if (tid < N) lsev = p.lse[((long)w.b * p.heads_total + br.head0 + w.g) * L + token_of(br, w, p.reso, tid)];
+        {
+            const int tap = tid / HD, ch = tid - tap * HD, cb = ch0 - br.c0 + ch;
+            wl0 = (tid >= 10 * HD || ch >= p.hd) ? 0.f : (tap < 9 ? br.lepe_w[cb * 9 + tap] : br.lepe_b[cb]);
+            const int i2 = tid + T, tap2 = i2 / HD, ch2 = i2 - tap2 * HD, cb2 = ch0 - br.c0 + ch2;
+            wl1 = (i2 >= 10 * HD || ch2 >= p.hd) ? 0.f : (tap2 < 9 ? br.lepe_w[cb2 * 9 + tap2] : br.lepe_b[cb2]);
         }
     };
-    f32x4 sa, da;
-    s_dp(0, sa, da);
-#pragma unroll
-    for (int qt = 0; qt < NT; ++qt) {
-        f32x4 sn = sa, dn = da;
-        if (qt + 1 < NT) s_dp(qt + 1, sn, dn);
-        const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_s[16 * qt + 4 * kq]);
-        const f32x4 de = *reinterpret_cast<const f32x4*>(&del_s[16 * qt + 4 * kq]);
-        f32x4 pr, ds;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            pr[r] = kvalid ? __expf(sa[r] * p.scale - ls[r]) : 0.f;
-            ds[r] = pr[r] * (da[r] - de[r]);
-        }
-        if (p.drop_p > 0.f) {                      // dS = P o (dP o M - delta); dV below takes P o M (pr is not used after it)
-            const long uid = attn_unit_id(p, br, w.b, w.g, w.win);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float m = attn_keep(p, uid, N, 16 * qt + 4 * kq + r, tk);
-                ds[r] = pr[r] * (da[r] * m - de[r]);
-                pr[r] *= m;
-            }
-        }
-        if constexpr (M16) {
-            const int q0row = 16 * qt + 4 * kq;
-            const float* dop = &Ds[q0row * LDT + li];
-            const float* qp = &QK[q0row * LDT + li];
-            const attn_s16x4 prb = pk4(pr), dsb = pk4(ds);
-            dVt[0] = mfma16(pk4(f32x4{dop[0], dop[LDT], dop[2 * LDT], dop[3 * LDT]}), prb, dVt[0]);
-            dVt[1] = mfma16(pk4(f32x4{dop[16], dop[LDT + 16], dop[2 * LDT + 16], dop[3 * LDT + 16]}), prb, dVt[1]);
-            dKt[0] = mfma16(pk4(f32x4{qp[0], qp[LDT], qp[2 * LDT], qp[3 * LDT]}), dsb, dKt[0]);
-            dKt[1] = mfma16(pk4(f32x4{qp[16], qp[LDT + 16], qp[2 * LDT + 16], qp[3 * LDT + 16]}), dsb, dKt[1]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (colok) VS[(q0row + r) * S + 16 * kw + li] = ds[r];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qrow = 16 * qt + 4 * kq + r;
-                const float* dop = &Ds[qrow * LDT + li];
-                const float* qp = &QK[qrow * LDT + li];
-                dVt[0] = mfma4(dop[0], pr[r], dVt[0]);
-                dVt[1] = mfma4(dop[16], pr[r], dVt[1]);
-                dKt[0] = mfma4(qp[0], ds[r], dKt[0]);
-                dKt[1] = mfma4(qp[16], ds[r], dKt[1]);
-                if (colok) VS[qrow * S + 16 * kw + li] = ds[r];
-            }
-        }
-        sa = sn;
-        da = dn;
-    }
-    // lane holds dV^T / dK^T [d = 16 df + 4 kq + e][key = tk]: add LePE^T(dO) to dV and store
-    if (kvalid) {
-        const int rr = thin ? 0 : tk / br.W_sp, cc = thin ? 0 : tk - rr * br.W_sp;          // thin stripes: unused
-#pragma unroll
-        for (int df = 0; df < 2; ++df) {
-            const int d0 = 16 * df + 4 * kq;
-            const f32x4 acc = thin ? lepe_taps4<true, -1>(br, Ds, Wl, rr, cc, tk, d0, dVt[df])
-                                   : lepe_taps4<false, -1>(br, Ds, Wl, rr, cc, tk, d0, dVt[df]);
-            if (d0 < p.hd) {
-                float* dst = dqkv_b + (long)lk * C3 + ch0 + d0;
-                stdq<Q16>(p, dst + p.C, dKt[df] * p.scale);
-                stdq<Q16>(p, dst + 2 * p.C, acc);
-            }
-        }
-    }
-    ATTN_STAMP(3);
-    __syncthreads();                                    // dS complete; Q image dead
 
-    // ---- P3: K image over Q, then dQ ----
+    ATTN_STAMP(0);
+    issue(item);
     {
-        float* kp = &QK[tk * LDT + 8 * kq];
-        *reinterpret_cast<f32x4*>(kp) = f32x4{kf[0], kf[1], kf[2], kf[3]};
-        *reinterpret_cast<f32x4*>(kp + 4) = f32x4{kf[4], kf[5], kf[6], kf[7]};
-    }
-    __syncthreads();
-    ATTN_STAMP(4);
-    {
-        const int qt = wave;
-        f32x4 dQt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const WgInfo w = decode_wg(p, item);
+        const AttnBranch& br = p.br[w.bi];
+        const int ch0 = br.c0 + w.g * p.hd, N = w.N;
+        float* dqkv_b = p.dqkv + (long)w.b * L * C3;
+        const bool thin = br.H_sp == 1 || br.W_sp == 1;       // wave-uniform
+        const int kw = wave;                               // key tile owned by this wave
+        const int tk = 16 * kw + li;                       // this lane's key token
+        const bool kvalid = tk < N;
+        const int lk = kvalid ? token_of(br, w, p.reso, tk) : 0;
+
+        // ---- A: registers -> LDS; delta ----
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            // columns beyond the stride read the head of the next row (finite) against K rows that are zero
-            const f32x4 ds = *reinterpret_cast<const f32x4*>(&VS[(16 * qt + li) * S + 16 * kt + 4 * kq]);
-            if constexpr (M16) {
-                const float* kp = &QK[(16 * kt + 4 * kq) * LDT + li];
-                const attn_s16x4 dsb = pk4(ds);
-                dQt[0] = mfma16(pk4(f32x4{kp[0], kp[LDT], kp[2 * LDT], kp[3 * LDT]}), dsb, dQt[0]);
-                dQt[1] = mfma16(pk4(f32x4{kp[16], kp[LDT + 16], kp[2 * LDT + 16], kp[3 * LDT + 16]}), dsb, dQt[1]);
-            } else {
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + it * T, row = idx >> 3, c4 = idx & 7;
+            *reinterpret_cast<f32x4*>(&QK[row * LDT + 4 * c4]) = qcv(qv[it]);
+            *reinterpret_cast<f32x4*>(&VS[row * LDT + 4 * c4]) = qcv(vv[it]);
+            *reinterpret_cast<f32x4*>(&Ds[row * LDT + 4 * c4]) = dv[it];
+            const f32x4 y4 = qcv(yv[it]);
+            const float part = oct_sum(dv[it][0] * y4[0] + dv[it][1] * y4[1] + dv[it][2] * y4[2] + dv[it][3] * y4[3]);
+            if (c4 == 0) {
+                del_s[row] = part;                          // rows >= N: 0
+                reinterpret_cast<int*>(Ds)[row * LDT + HD] = bbits[it];
+            }
+        }
+        {
+            // LePE bias gradient = sum of dO over the window's tokens: this thread's two rows share its channel chunk (lane & 7); the
+            // wave's eight row groups meet by DPP / swaps, the waves in the [NT][HD] patch behind the taps (summed when stored)
+            f32x4 bs = dv[0] + dv[1];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float* kp = &QK[(16 * kt + 4 * kq + r) * LDT + li];
-                    dQt[0] = mfma4(kp[0], ds[r], dQt[0]);
-                    dQt[1] = mfma4(kp[16], ds[r], dQt[1]);
+            for (int e = 0; e < 4; ++e) {
+                float v = bs[e];
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+                bs[e] = xor32_sum(xor16_sum(v));
+            }
+            if (lane < 8) *reinterpret_cast<f32x4*>(&Gl[(9 + wave) * HD + 4 * lane]) = bs;
+        }
+        if (tid < 8) *reinterpret_cast<f32x4*>(&VS[NP * LDT + 4 * tid]) = f32x4{0.f, 0.f, 0.f, 0.f};      // the zero row behind the V image
+        if (tid < NP) lse_s[tid] = lsev;
+        if (tid < 10 * HD) Wl[tid] = wl0;
+        if (tid + T < 10 * HD) Wl[tid + T] = wl1;
+        float kf[8], vf[8];
+        {
+            const f32x4 k0 = qcv(k0r), k1 = qcv(k1r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                kf[e] = k0[e];
+                kf[4 + e] = k1[e];
+            }
+        }
+        lds_barrier();
+        ATTN_STAMP(1);
+        {
+            const float* vp = &VS[tk * LDT + 8 * kq];
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp), v1 = *reinterpret_cast<const f32x4*>(vp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                vf[e] = v0[e];
+                vf[4 + e] = v1[e];
+            }
+        }
+
+        ATTN_STAMP(2);
+        // ---- B: LePE conv weight gradient of this (window, head): dW[tap][ch] = sum_t dO[t][ch] V[nbr(t, tap)][ch] ----
+        // The live taps (all nine, or the three along a one-token-wide stripe) are dealt to the waves round robin.  A lane =
+        // (token 8 i + j, 16-B channel chunk c4), j = lane >> 3: per step i the wave covers eight consecutive image rows, so every
+        // LDS address is a lane constant plus a compile-time offset.  Whether the neighbour (r + ky - 1, c + kx - 1) lies inside
+        // the window comes from the token's border bits (pad column of the dO image, written while staging); a neighbour outside
+        // reads the zero row instead.  The step loop is branch-free and its reads are issued in batches: as a loop of dependent
+        // ds_read -> wait -> fma steps this phase took 14 - 21 k cycles per unit.
+        {
+            const int c4 = lane & 7, tj = lane >> 3;
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+            constexpr int NTAP = (9 + NT - 1) / NT;              // taps per wave (at most)
+            const int nlive = thin ? 3 : 9;
+            int ntap = 0;                                        // wave-uniform
+            int off[NTAP], need[NTAP], tapid[NTAP];
+#pragma unroll
+            for (int k = 0; k < NTAP; ++k) {
+                const int j = wv + k * NT;                       // index into the live taps
+                const int tap = !thin ? j : (br.H_sp == 1 ? 3 + j : 3 * j + 1);
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                tapid[k] = tap;
+                off[k] = ((ky - 1) * br.W_sp + (kx - 1)) * LDT;
+                need[k] = (ky == 0 ? 1 : 0) | (ky == 2 ? 2 : 0) | (kx == 0 ? 4 : 0) | (kx == 2 ? 8 : 0) | 16;
+                if (j < nlive) ntap = k + 1;
+            }
+            const float* gbase = &Ds[tj * LDT + 4 * c4];
+            const float* vbase = &VS[tj * LDT + 4 * c4];
+            const float* zrow = &VS[NP * LDT + 4 * c4];
+            const int* mbase = reinterpret_cast<const int*>(&Ds[tj * LDT + HD]);
+            f32x4 acc[NTAP];
+#pragma unroll
+            for (int k = 0; k < NTAP; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto taps = [&](auto kc) {
+                constexpr int KC = decltype(kc)::value;
+                const float* gp = gbase;
+                const float* vp0 = vbase;
+                const int* mp = mbase;
+#pragma unroll 1
+                for (int i0 = 0; i0 < 2 * NT; i0 += 2) {         // two steps at a time
+                    f32x4 g4[2], v4[2][KC];
+                    int m[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        g4[u] = *reinterpret_cast<const f32x4*>(gp + 8 * u * LDT);
+                        m[u] = mp[8 * u * LDT];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int k = 0; k < KC; ++k) {
+                            const bool ok = (m[u] & need[k]) == need[k];
+                            v4[u][k] = *reinterpret_cast<const f32x4*>(ok ? vp0 + 8 * u * LDT + off[k] : zrow);
+                        }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int k = 0; k < KC; ++k) acc[k] += g4[u] * v4[u][k];
+                    gp += 16 * LDT;
+                    vp0 += 16 * LDT;
+                    mp += 16 * LDT;
+                }
+            };
+            if (ntap == 1) taps(std::integral_constant<int, 1>{});
+            else if (NTAP >= 2 && ntap == 2) taps(std::integral_constant<int, (NTAP >= 2 ? 2 : 1)>{});
+            else if (NTAP >= 3 && ntap == 3) taps(std::integral_constant<int, (NTAP >= 3 ? 3 : 1)>{});
+            // the eight token slots (lanes that share lane & 7) meet: DPP inside the row, row / half swaps across
+#pragma unroll
+            for (int k = 0; k < NTAP; ++k) {
+                if (k >= ntap) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[k][e];
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+                    acc[k][e] = xor32_sum(xor16_sum(v));
+                }
+                if (lane < 8) *reinterpret_cast<f32x4*>(&Gl[tapid[k] * HD + 4 * lane]) = acc[k];
+            }
+            if (thin && wv == 3 % NT) {                          // the six taps that never fall inside a thin stripe
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int ky = tap / 3, kx = tap - 3 * ky;
+                    const bool dead = br.H_sp == 1 ? ky != 1 : kx != 1;
+                    if (dead && lane < 8) *reinterpret_cast<f32x4*>(&Gl[tap * HD + 4 * lane]) = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
         }
-        const int tq = 16 * qt + li;
-        if (tq < N) {
-            float* dst = dqkv_b + (long)token_of(br, w, p.reso, tq) * C3 + ch0 + 4 * kq;
-            if (4 * kq < p.hd) stdq<Q16>(p, dst, dQt[0] * p.scale);
-            if (16 + 4 * kq < p.hd) stdq<Q16>(p, dst + 16, dQt[1] * p.scale);
-        }
-    }
-    ATTN_STAMP(5);
+        ATTN_STAMP(3);
+        lds_barrier();                                      // V image dead (VS becomes the dS image); the unit's LePE gradient is complete
+        {
+            // partial-slab row of (b, window): columns [channel of the branch][tap] then [bias]; this head's 9 hd + hd values are
+            // contiguous, so thread i stores element i (coalesced) from the [tap][d] patch
+            const int cb = br.heads * p.hd;
+            float* row = br.dw_part + ((long)w.b * br.nWin + w.win) * p.slab_rows * (cb * 10);
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-        if (tid + u * NTHREADS < 10 * HD) store_lepe_partial(p, br, w, 0, tid + u * NTHREADS, lepe_part[u]);
-    ATTN_STAMP(6);
+            for (int i = tid; i < 10 * HD; i += T) {
+                if (i < 9 * p.hd) {
+                    const int d = i / 9, tap = i - 9 * d;
+                    row[w.g * p.hd * 9 + i] = Gl[tap * HD + d];
+                } else if (i >= 9 * HD && i < 9 * HD + p.hd) {
+                    float bsum = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) bsum += Gl[(9 + k) * HD + (i - 9 * HD)];
+                    row[cb * 9 + w.g * p.hd + (i - 9 * HD)] = bsum;
+                }
+            }
+        }
+
+        // ---- C: fused S / dP -> P, dS -> dV^T, dK^T ----
+        f32x4 dVt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4 dKt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const bool colok = 16 * kw + li < S;               // dS columns beyond the stride would land in the next row
+        const attn_bf16x8 kb = pk8(f32x4{kf[0], kf[1], kf[2], kf[3]}, f32x4{kf[4], kf[5], kf[6], kf[7]});       // M16 only
+        const attn_bf16x8 vb = pk8(f32x4{vf[0], vf[1], vf[2], vf[3]}, f32x4{vf[4], vf[5], vf[6], vf[7]});
+        auto s_dp = [&](int qt, f32x4& sa, f32x4& da) {
+            const float* qp = &QK[(16 * qt + li) * LDT + 8 * kq];
+            const float* dp = &Ds[(16 * qt + li) * LDT + 8 * kq];
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(qp), q1 = *reinterpret_cast<const f32x4*>(qp + 4);
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(dp), d1 = *reinterpret_cast<const f32x4*>(dp + 4);
+            sa = da = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (M16) {
+                sa = mfma32(pk8(q0, q1), kb, sa);
+                da = mfma32(pk8(d0, d1), vb, da);
+                return;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sa = mfma4(q0[e], kf[e], sa);               // S[q][key] = sum_d Q[q][d] K[key][d]
+                da = mfma4(d0[e], vf[e], da);               // dP[q][key] = sum_d dO[q][d] V[key][d]
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sa = mfma4(q1[e], kf[4 + e], sa);
+                da = mfma4(d1[e], vf[4 + e], da);
+            }
+        };
+        unsigned keep = ~0u;                                // attention dropout only: bit 4 qt + r = keep (query 16 qt + 4 kq + r, key tk)
+        if (p.drop_p > 0.f)
+            keep = attn_keep_bits<4 * NT>(p, attn_unit_id(p, br, w.b, w.g, w.win), N,
+                                          [&](int i, int& q_, int& k_) { q_ = 16 * (i >> 2) + 4 * kq + (i & 3); k_ = tk; });
+        {
+            f32x4 sa, da;
+            s_dp(0, sa, da);
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt) {
+                f32x4 sn = sa, dn = da;
+                if (qt + 1 < NT) s_dp(qt + 1, sn, dn);
+                const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_s[16 * qt + 4 * kq]);
+                const f32x4 de = *reinterpret_cast<const f32x4*>(&del_s[16 * qt + 4 * kq]);
+                f32x4 pr, ds;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pr[r] = kvalid ? __expf(sa[r] * p.scale - ls[r]) : 0.f;
+                    ds[r] = pr[r] * (da[r] - de[r]);
+                }
+                if (p.drop_p > 0.f) {                      // dS = P o (dP o M - delta); dV below takes P o M (pr is not used after it)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float m = (keep >> (4 * qt + r)) & 1u ? p.drop_scale : 0.f;
+                        ds[r] = pr[r] * (da[r] * m - de[r]);
+                        pr[r] *= m;
+                    }
+                }
+                const int q0row = 16 * qt + 4 * kq;
+                if constexpr (M16) {
+                    const float* dop = &Ds[q0row * LDT + li];
+                    const float* qp = &QK[q0row * LDT + li];
+                    const attn_s16x4 prb = pk4(pr), dsb = pk4(ds);
+                    dVt[0] = mfma16(pk4(f32x4{dop[0], dop[LDT], dop[2 * LDT], dop[3 * LDT]}), prb, dVt[0]);
+                    dVt[1] = mfma16(pk4(f32x4{dop[16], dop[LDT + 16], dop[2 * LDT + 16], dop[3 * LDT + 16]}), prb, dVt[1]);
+                    dKt[0] = mfma16(pk4(f32x4{qp[0], qp[LDT], qp[2 * LDT], qp[3 * LDT]}), dsb, dKt[0]);
+                    dKt[1] = mfma16(pk4(f32x4{qp[16], qp[LDT + 16], qp[2 * LDT + 16], qp[3 * LDT + 16]}), dsb, dKt[1]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float* dop = &Ds[(q0row + r) * LDT + li];
+                        const float* qp = &QK[(q0row + r) * LDT + li];
+                        dVt[0] = mfma4(dop[0], pr[r], dVt[0]);
+                        dVt[1] = mfma4(dop[16], pr[r], dVt[1]);
+                        dKt[0] = mfma4(qp[0], ds[r], dKt[0]);
+                        dKt[1] = mfma4(qp[16], ds[r], dKt[1]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (colok && q0row + r < N) VS[(q0row + r) * S + 16 * kw + li] = ds[r];
+                sa = sn;
+                da = dn;
+            }
+        }
+        // lane holds dV^T / dK^T [d = 16 df + 4 kq + e][key = tk]: add LePE^T(dO) to dV and store
+        if (kvalid) {
+            const int rr = thin ? 0 : fdiv(tk, br.m_Wsp), cc = thin ? 0 : tk - rr * br.W_sp;          // thin stripes: unused
+#pragma unroll
+            for (int df = 0; df < 2; ++df) {
+                const int d0 = 16 * df + 4 * kq;
+                const f32x4 acc = thin ? lepe_taps4<true, -1>(br, Ds, Wl, rr, cc, tk, d0, dVt[df])
+                                       : lepe_taps4<false, -1>(br, Ds, Wl, rr, cc, tk, d0, dVt[df]);
+                if (d0 < p.hd) {
+                    float* dst = dqkv_b + (long)lk * C3 + ch0 + d0;
+                    stdq<Q16>(p, dst + p.C, dKt[df] * p.scale);
+                    stdq<Q16>(p, dst + 2 * p.C, acc);
+                }
+            }
+        }
+        ATTN_STAMP(4);
+        lds_barrier();                                      // dS complete; Q image dead
+
+        // ---- D: K image over Q, then dQ ----
+        {
+            float* kp = &QK[tk * LDT + 8 * kq];
+            *reinterpret_cast<f32x4*>(kp) = f32x4{kf[0], kf[1], kf[2], kf[3]};
+            *reinterpret_cast<f32x4*>(kp + 4) = f32x4{kf[4], kf[5], kf[6], kf[7]};
+        }
+        lds_barrier();
+        ATTN_STAMP(5);
+        {
+            const int qt = wave;
+            const int tq = 16 * qt + li;
+            const int qrow = min(tq, N - 1);                // padded queries re-read the last row (their columns are discarded)
+            f32x4 dQt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                // columns beyond the stride read the head of the next row / the zeroed tail (finite) against K rows that are zero
+                const f32x4 ds = *reinterpret_cast<const f32x4*>(&VS[qrow * S + 16 * kt + 4 * kq]);
+                if constexpr (M16) {
+                    const float* kp = &QK[(16 * kt + 4 * kq) * LDT + li];
+                    const attn_s16x4 dsb = pk4(ds);
+                    dQt[0] = mfma16(pk4(f32x4{kp[0], kp[LDT], kp[2 * LDT], kp[3 * LDT]}), dsb, dQt[0]);
+                    dQt[1] = mfma16(pk4(f32x4{kp[16], kp[LDT + 16], kp[2 * LDT + 16], kp[3 * LDT + 16]}), dsb, dQt[1]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float* kp = &QK[(16 * kt + 4 * kq + r) * LDT + li];
+                        dQt[0] = mfma4(kp[0], ds[r], dQt[0]);
+                        dQt[1] = mfma4(kp[16], ds[r], dQt[1]);
+                    }
+                }
+            }
+            if (tq < N) {
+                float* dst = dqkv_b + (long)token_of(br, w, p.reso, tq) * C3 + ch0 + 4 * kq;
+                if (4 * kq < p.hd) stdq<Q16>(p, dst, dQt[0] * p.scale);
+                if (16 + 4 * kq < p.hd) stdq<Q16>(p, dst + 16, dQt[1] * p.scale);
+            }
+        }
+        ATTN_STAMP(6);
+    }
 }
 
 // =====================================================================================
@@ -788,7 +1119,7 @@ __device__ __forceinline__ BigWg decode_big(const AttnParams& p, int wg, int nbl
 }
 
 __device__ __forceinline__ int token_of2(const AttnBranch& br, int ih, int iw, int reso, int t) {
-    int r = t / br.W_sp, c = t - r * br.W_sp;
+    const int r = br.W_sp > 1 ? fdiv(t, br.m_Wsp) : t, c = t - r * br.W_sp;
     return (ih * br.H_sp + r) * reso + iw * br.W_sp + c;
 }
 
@@ -797,7 +1128,7 @@ template <int ST>
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
     constexpr bool Q16 = (ST & 1) != 0, Y16 = (ST & 2) != 0, M16 = (ST & 4) != 0;      // storage of qkv / dqkv and of y, bf16 MFMAs (see AttnParams)
     (void)Q16; (void)Y16; (void)M16;
-    const int L = p.reso * p.reso, C3 = 3 * p.C;
+    const int L = p.reso * p.reso;
     const long item = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
     const int j = threadIdx.x & 7;
     const long total = (long)p.B * p.heads_total * L;
@@ -810,28 +1141,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
         const int bi = (p.nbranch > 1 && hg >= p.br[1].head0) ? 1 : 0;
         const AttnBranch& br = p.br[bi];
         const int g = hg - br.head0;
-        const int ch0 = br.c0 + g * p.hd + 4 * j, cb = g * p.hd + 4 * j;
-        const int yy = l / p.reso, xx = l - yy * p.reso;
-        const int ih = yy / br.H_sp, r = yy - ih * br.H_sp, iw = xx / br.W_sp, c = xx - iw * br.W_sp;
+        const int ch0 = br.c0 + g * p.hd + 4 * j;
         if (4 * j < p.hd) {
-        f32x4 lepe = *reinterpret_cast<const f32x4*>(br.lepe_b + cb);
+            const f32x4 yv = qcv(ldy_raw<Y16>(p, p.y_in + ((long)b * L + l) * p.C + ch0));
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(p.dy + ((long)b * L + l) * p.C + ch0);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int r2 = r + ky - 1, c2 = c + kx - 1;
-                if ((unsigned)r2 < (unsigned)br.H_sp && (unsigned)c2 < (unsigned)br.W_sp) {
-                    const int l2 = (ih * br.H_sp + r2) * p.reso + iw * br.W_sp + c2;
-                    const f32x4 v = ldq<Q16>(p, p.qkv + ((long)b * L + l2) * C3 + 2 * p.C + ch0);
-                    const int tap = ky * 3 + kx;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) lepe[e] += br.lepe_w[(cb + e) * 9 + tap] * v[e];
-                }
-            }
-        const f32x4 yv = qcv(ldy_raw<Y16>(p, p.y_in + ((long)b * L + l) * p.C + ch0));
-        const f32x4 dv = *reinterpret_cast<const f32x4*>(p.dy + ((long)b * L + l) * p.C + ch0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) part += dv[e] * (yv[e] - lepe[e]);
+            for (int e = 0; e < 4; ++e) part += dv[e] * yv[e];
         }
         out_idx = ((long)b * p.heads_total + hg) * L + l;
     }
@@ -955,7 +1270,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p, int nblk
         __syncthreads();
     }
     if (kvalid) {
-        const int rr = tk / br.W_sp, cc = tk - rr * br.W_sp;
+        const int rr = br.W_sp > 1 ? fdiv(tk, br.m_Wsp) : tk, cc = tk - rr * br.W_sp;
 #pragma unroll
         for (int df = 0; df < 2; ++df) {
             const int d0 = 16 * df + 4 * kq, cb = w.g * p.hd + d0;
@@ -1112,7 +1427,7 @@ __global__ __launch_bounds__(256) void lepe_wgrad_kernel(AttnParams p) {
     if (live) {
 #pragma unroll 4
         for (int t = t0; t < t1; ++t) {
-            const int rr = t / br.W_sp, cc = t - rr * br.W_sp;
+            const int rr = br.W_sp > 1 ? fdiv(t, br.m_Wsp) : t, cc = t - rr * br.W_sp;
             const f32x4 g4 = *reinterpret_cast<const f32x4*>(dy_b + (long)token_of(br, w, p.reso, t) * p.C);
             if (tap == 9) {
                 acc += g4;
@@ -1198,6 +1513,10 @@ int fill_params(AttnParams& p, const char* who, int B, int reso, int C, int nbra
         br.nW = reso / W_sp;
         br.nWin = (reso / H_sp) * (reso / W_sp);
         br.wg_begin = wg;
+        br.m_heads = fdiv_magic(br.heads); br.m_nWin = fdiv_magic(br.nWin); br.m_nW = fdiv_magic(br.nW); br.m_Wsp = fdiv_magic(W_sp);
+        CSWIN_REQUIRE((long)B * br.nWin * heads[i] < (1 << 20) && H_sp * W_sp < (1 << 12) && br.nWin < (1 << 12) && heads[i] < (1 << 12),
+                      CSWIN_ERR_UNSUPPORTED, "%s: %ld units of %d tokens exceed the index arithmetic's range", who,
+                      (long)B * br.nWin * heads[i], H_sp * W_sp);
         wg += B * br.nWin * heads[i];
         heads_total += heads[i];
         if (N0 < 0) N0 = H_sp * W_sp;
@@ -1246,35 +1565,64 @@ int launch_fwd(const AttnParams& p, int nwg, hipStream_t st) {
          : p.qkv_bf16 ? launch_fwd_q<NT, 1>(p, nwg, st) : launch_fwd_q<NT, 0>(p, nwg, st);
 }
 
+// forward for windows of up to 128 tokens: items = units, or 2 x units with the query tiles split over two workgroups
+template <int NT, int ST>
+int launch_fwd3_q(const AttnParams& p, int nwg, hipStream_t st) {
+    const size_t lds = (size_t)(2 * 16 * NT * LDT + 10 * HD) * sizeof(float);
+    static_assert((2 * 16 * NT * LDT + 10 * HD) * sizeof(float) <= 64 * 1024, "no dynamic-LDS opt-in on this path");
+    if constexpr (NT >= 6) {
+        // few units relative to the CUs (stage 3: 384 units of 7 query tiles): split the query tiles over two workgroups per unit
+        const int force = cswin_tuning().attn_fwd_qsplit;                            // tuning aid: 1 or 2
+        if (force ? force == 2 : (nwg < 1024 && nwg % 256 != 0)) {
+            hipLaunchKernelGGL((attn_fwd3_kernel<NT, 2, ST>), dim3(2 * nwg), dim3(64 * ((NT + 1) / 2)), lds, st, p, nwg);
+            return CSWIN_OK;
+        }
+    }
+    hipLaunchKernelGGL((attn_fwd3_kernel<NT, 1, ST>), dim3(nwg), dim3(64 * NT), lds, st, p, nwg);
+    return CSWIN_OK;
+}
+
+template <int NT>
+int launch_fwd3(const AttnParams& p, int nwg, hipStream_t st) {
+    return p.qkv_bf16 == 7 ? launch_fwd3_q<NT, 7>(p, nwg, st) : p.qkv_bf16 == 3 ? launch_fwd3_q<NT, 3>(p, nwg, st)
+         : p.qkv_bf16 ? launch_fwd3_q<NT, 1>(p, nwg, st) : launch_fwd3_q<NT, 0>(p, nwg, st);
+}
+
 inline int ds_stride_for(int N) {            // smallest stride >= N with stride = 4 (mod 8): 16-B aligned rows, and the four
     int s = (N + 3) / 4 * 4;                 // row groups of a dS column write land in distinct banks
     while (s % 8 != 4) s += 4;
     return s;
 }
 
-template <int NT, int Q16>
-int launch_bwd2_q(const AttnParams& p, int nwg, hipStream_t st) {
+inline int vs_floats_for(int NT, int N, int S) {     // V image [16 NT + 1][LDT] (last row zero), later dS [N][S] + 16 NT finite floats behind it
+    const int NP = 16 * NT;
+    const int a = N * S + NP, b = (NP + 1) * LDT;
+    return ((a > b ? a : b) + 3) / 4 * 4;
+}
+
+template <int NT, int ST>
+int launch_bwd3_q(const AttnParams& p, int nwg, hipStream_t st) {
     constexpr int NP = 16 * NT;
-    const int S = p.ds_stride;
-    const int vs_min = NP * LDT + NT * 10 * HD;
-    const size_t lds = (size_t)(2 * NP * LDT + (NP * S > vs_min ? NP * S : vs_min) + 2 * NP + 10 * HD) * sizeof(float);
+    const size_t lds = (size_t)(2 * NP * LDT + p.vs_floats + 2 * NP + (19 + NT) * HD) * sizeof(float);
     if (lds > 64 * 1024) {
         // once per process and instantiation, thread-safe: reserve the largest footprint this NT can ask for (N = 16 NT tokens)
         static std::once_flag once;
         static hipError_t status = hipSuccess;
         constexpr int SMAX = ((NP + 3) / 4 * 4) + 8;
-        constexpr size_t lds_max = (size_t)(2 * NP * LDT + NP * SMAX + 2 * NP + 10 * HD) * sizeof(float);
-        std::call_once(once, [&] { status = hipFuncSetAttribute((const void*)attn_bwd2_kernel<NT, Q16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); });
+        constexpr size_t lds_max = (size_t)(2 * NP * LDT + (NP * SMAX + NP + 4 > (NP + 1) * LDT ? NP * SMAX + NP + 4 : (NP + 1) * LDT) + 2 * NP + (19 + NT) * HD) * sizeof(float);
+        std::call_once(once, [&] {
+            status = hipFuncSetAttribute((const void*)attn_bwd3_kernel<NT, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        });
         if (status != hipSuccess) { cswin_set_error("attn_bwd: cannot reserve %zu B LDS: %s", lds_max, hipGetErrorString(status)); return CSWIN_ERR_HIP; }
     }
-    hipLaunchKernelGGL((attn_bwd2_kernel<NT, Q16>), dim3(nwg), dim3(64 * NT), lds, st, p);
+    hipLaunchKernelGGL((attn_bwd3_kernel<NT, ST>), dim3(nwg), dim3(64 * NT), lds, st, p);
     return CSWIN_OK;
 }
 
 template <int NT>
-int launch_bwd2(const AttnParams& p, int nwg, hipStream_t st) {
-    return p.qkv_bf16 == 7 ? launch_bwd2_q<NT, 7>(p, nwg, st) : p.qkv_bf16 == 3 ? launch_bwd2_q<NT, 3>(p, nwg, st)
-         : p.qkv_bf16 ? launch_bwd2_q<NT, 1>(p, nwg, st) : launch_bwd2_q<NT, 0>(p, nwg, st);
+int launch_bwd3(const AttnParams& p, int nwg, hipStream_t st) {
+    return p.qkv_bf16 == 7 ? launch_bwd3_q<NT, 7>(p, nwg, st) : p.qkv_bf16 == 3 ? launch_bwd3_q<NT, 3>(p, nwg, st)
+         : p.qkv_bf16 ? launch_bwd3_q<NT, 1>(p, nwg, st) : launch_bwd3_q<NT, 0>(p, nwg, st);
 }
 
 template <int Q16>
@@ -1301,7 +1649,7 @@ void cswin_debug_set_attn_stamps(void* p) { g_attn_stamps = (long long*)p; }
 
 // qkv (B, L, 3C) -> y (B, L, C), lse (B, heads_total, L).  nbranch = 2: branch i uses channels
 // [i*C/2, (i+1)*C/2) with stripe mode idx[i]; nbranch = 1: whole C, idx[0] (normally -1).
-int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, float* y, float* lse,
+int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, float* y, float* y0, float* lse,
                    int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split, float scale, float drop_p,
                    unsigned long long drop_seed, int qkv_bf16, void* stream) {
     AttnParams p = {};
@@ -1315,13 +1663,13 @@ int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* co
     if (rc) return rc;
     CSWIN_REQUIRE(qkv && y && lse && lepe_w && lepe_b, CSWIN_ERR_SHAPE, "attn_fwd: null pointer");
     for (int i = 0; i < nbranch; ++i) { p.br[i].lepe_w = lepe_w[i]; p.br[i].lepe_b = lepe_b[i]; }
-    p.qkv = qkv; p.y = y; p.lse = lse;
+    p.qkv = qkv; p.y = y; p.y0 = y0; p.lse = lse;
     p.stamps = g_attn_stamps;
     hipStream_t st = (hipStream_t)stream;
     switch (nt) {
-        case 1: case 2: case 3: case 4: rc = launch_fwd<4>(p, nwg, st); break;
-        case 5: case 6: rc = launch_fwd<6>(p, nwg, st); break;
-        case 7: rc = launch_fwd<7>(p, nwg, st); break;
+        case 1: case 2: case 3: case 4: rc = launch_fwd3<4>(p, nwg, st); break;
+        case 5: case 6: rc = launch_fwd3<6>(p, nwg, st); break;
+        case 7: rc = launch_fwd3<7>(p, nwg, st); break;
         case 8: case 9: rc = launch_fwd<9>(p, nwg, st); break;
         case 10: case 11: case 12: rc = launch_fwd<12>(p, nwg, st); break;
         case 13: case 14: case 15: rc = launch_fwd<15>(p, nwg, st); break;
@@ -1347,7 +1695,7 @@ size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* 
 
 // dqkv (B, L, 3C) is fully overwritten; dlepe_w[i] (Cb,9) and dlepe_b[i] (Cb) are overwritten.
 int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, const float* lse,
-                   const float* y, const float* dy, float* dqkv, float* const* dlepe_w, float* const* dlepe_b,
+                   const float* y0, const float* dy, float* dqkv, float* const* dlepe_w, float* const* dlepe_b,
                    void* workspace, size_t ws_bytes, int B, int reso, int C, int nbranch, const int* heads, const int* idx,
                    int split, float scale, cswin_reduce_job* deferred, float drop_p, unsigned long long drop_seed, int qkv_bf16,
                    void* stream) {
@@ -1362,7 +1710,7 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
     if (rc) return rc;
     CSWIN_REQUIRE(qkv && lse && dy && dqkv && lepe_w && dlepe_w && dlepe_b, CSWIN_ERR_SHAPE, "attn_bwd: null pointer");
     CSWIN_REQUIRE(workspace && ws_bytes >= cswin_attn_bwd_workspace(B, reso, C, nbranch, heads, idx, split), CSWIN_ERR_WORKSPACE, "attn_bwd: workspace too small");
-    CSWIN_REQUIRE(y && lepe_b, CSWIN_ERR_SHAPE, "attn_bwd: the forward output y and lepe_b are required");
+    CSWIN_REQUIRE(y0 && lepe_b, CSWIN_ERR_SHAPE, "attn_bwd: y0 (the forward's output without the LePE term) and lepe_b are required");
     const bool two_pass = nt > 7 || force_two_pass();
     p.slab_rows = two_pass ? LW_SUB : 1;
     p.ds_stride = ds_stride_for(p.br[0].H_sp * p.br[0].W_sp);
@@ -1372,7 +1720,7 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
         p.br[i].dw_part = (float*)workspace + (size_t)p.br[i].wg_begin * 10 * HD * p.slab_rows;
     }
     p.stamps = g_attn_stamps;
-    p.y_in = y;
+    p.y_in = y0;
     p.delta = (float*)workspace + (size_t)nwg * 10 * HD * p.slab_rows;
     p.qkv = qkv; p.lse = const_cast<float*>(lse); p.dy = dy; p.dqkv = dqkv;
     hipStream_t st = (hipStream_t)stream;
@@ -1386,10 +1734,11 @@ int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* co
         else launch_bwd_two_pass<0>(p, items, nwg, nblk, st);
         rc = CSWIN_OK;
     } else {
+        const int Ntok = p.br[0].H_sp * p.br[0].W_sp;
         switch (nt) {
-            case 1: case 2: case 3: case 4: rc = launch_bwd2<4>(p, nwg, st); break;
-            case 5: case 6: rc = launch_bwd2<6>(p, nwg, st); break;
-            default: rc = launch_bwd2<7>(p, nwg, st); break;
+            case 1: case 2: case 3: case 4: p.vs_floats = vs_floats_for(4, Ntok, p.ds_stride); rc = launch_bwd3<4>(p, nwg, st); break;
+            case 5: case 6: p.vs_floats = vs_floats_for(6, Ntok, p.ds_stride); rc = launch_bwd3<6>(p, nwg, st); break;
+            default: p.vs_floats = vs_floats_for(7, Ntok, p.ds_stride); rc = launch_bwd3<7>(p, nwg, st); break;
         }
     }
     if (rc) return rc;

@@ -395,17 +395,18 @@ class _StripeAttention(Function):
         if L != reso * reso:
             raise ValueError("flatten img_tokens has wrong size")
         y = torch.empty(B, L, C, dtype=torch.float32, device=qkv.device)
+        y0 = torch.empty_like(y) if any(ctx.needs_input_grad) else None          # P V without LePE: the backward's delta term
         lse = torch.empty(B, sum(heads), L, dtype=torch.float32, device=qkv.device)
-        call("cswin_attn_fwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(y), ptr(lse), B, reso, C, nb,
+        call("cswin_attn_fwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(y), ptr(y0), ptr(lse), B, reso, C, nb,
              _int_array(heads), _int_array(idx), split, float(scale or 0.0), drop[0], drop[1], int(q16), stream())
-        ctx.save_for_backward(qkv, lse, y, *ws_, *bs_)
+        ctx.save_for_backward(qkv, lse, y0, *ws_, *bs_)
         ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0), drop)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        qkv, lse, y, *wb_ = ctx.saved_tensors
+        qkv, lse, y0, *wb_ = ctx.saved_tensors
         reso, split, idx, heads, scale, drop = ctx.meta
         dy = dev_f32(dy)
         nb = len(idx)
@@ -418,7 +419,7 @@ class _StripeAttention(Function):
         ha, ia = _int_array(heads), _int_array(idx)
         nbytes = lib().cswin_attn_bwd_workspace(B, reso, C, nb, ha, ia, split)
         ws = _ws(nbytes, qkv.device)
-        call("cswin_attn_bwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(lse), ptr(y), ptr(dy), ptr(dqkv), _ptr_array(dws),
+        call("cswin_attn_bwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(lse), ptr(y0), ptr(dy), ptr(dqkv), _ptr_array(dws),
              _ptr_array(dbs), ptr(ws), nbytes, B, reso, C, nb, ha, ia, split, scale, None, drop[0], drop[1], int(qkv.dtype == torch.bfloat16), stream())
         return (dqkv, None, None, None, None, None, None) + tuple(d.view(d.shape[0], 1, 3, 3) for d in dws) + tuple(dbs)
 
@@ -473,8 +474,9 @@ class _CSWinBlock(Function):
         qkv = E16(B, L, 3 * C)
         call("cswin_linear_fwd", ptr(h1), None, 0, pq, ptr(bqkv), ptr(qkv), None, None, None, 1, M, 3 * C, C, precision(), io_xy | fq, st)
         att, lse = E16(B, L, C), E(B, sum(heads), L)
+        att0 = E16(B, L, C) if any(ctx.needs_input_grad) else None       # P V without LePE: the attention backward's delta term
         ha, ia = _int_array(heads), _int_array(idx)
-        call("cswin_attn_fwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(att), ptr(lse), B, reso, C, nb, ha, ia, split,
+        call("cswin_attn_fwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(att), ptr(att0), ptr(lse), B, reso, C, nb, ha, ia, split,
              float(scale or 0.0), drop[0], drop[1], 7 if s16 else 0, st)
         x1 = torch.empty_like(x)
         call("cswin_linear_fwd", ptr(att), None, 0, pp, ptr(bp), ptr(x1), None, ptr(x), ptr(rs1), L, M, C, C, precision(), io_x | fp, st)
@@ -485,14 +487,14 @@ class _CSWinBlock(Function):
         call("cswin_linear_fwd", ptr(h2), None, 0, p1, ptr(bb1), ptr(pre), ptr(act), None, None, 1, M, Hd, C, precision(), io_xy | f1, st)
         y = torch.empty_like(x)
         call("cswin_linear_fwd", ptr(act), None, 0, p2, ptr(bb2), ptr(y), None, ptr(x1), ptr(rs2), L, M, C, Hd, precision(), io_x | f2, st)
-        ctx.save_for_backward(x, m1, r1, h1, qkv, lse, att, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lw, *lb)
+        ctx.save_for_backward(x, m1, r1, h1, qkv, lse, att, att0, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lw, *lb)
         ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0), bqkv is not None, s16, drop)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        (x, m1, r1, h1, qkv, lse, att, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lwb) = ctx.saved_tensors
+        (x, m1, r1, h1, qkv, lse, att, att0, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lwb) = ctx.saved_tensors
         reso, split, idx, heads, scale, has_qkv_bias, s16, drop = ctx.meta
         lw, lb = lwb[:len(idx)], lwb[len(idx):]
         dy = dev_f32(dy)
@@ -562,7 +564,7 @@ class _CSWinBlock(Function):
         ha, ia = _int_array(heads), _int_array(idx)
         naw = h.cswin_attn_bwd_workspace(B, reso, C, nb, ha, ia, split)
         aws = _ws(naw, dev)
-        call("cswin_attn_bwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(lse), ptr(att), ptr(datt), ptr(dqkv),
+        call("cswin_attn_bwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(lse), ptr(att0), ptr(datt), ptr(dqkv),
              _ptr_array(dlw), _ptr_array(dlb), ptr(aws), naw, B, reso, C, nb, ha, ia, split, scale, J(6), drop[0], drop[1], 7 if s16 else 0, st)
         dwqkv = torch.empty_like(wqkv)
         dbqkv = E(3 * C) if has_qkv_bias else None

@@ -56,11 +56,15 @@ int cswin_device_ok(void); /* 1 if the current HIP device is gfx950 */
  * qkv (B, L, 3C) = output of the qkv Linear, channel layout [q | k | v] (:169).
  * nbranch = 2: branch i works on channels [i*C/2, (i+1)*C/2) of each of q,k,v with stripe mode idx[i]
  *   (0: H_sp=reso, W_sp=split; 1: H_sp=split, W_sp=reso; :43-48) and heads[i] heads;
- * nbranch = 1: whole C, idx[0] = -1 (window = whole map).  Head dim must be 32.
+ * nbranch = 1: whole C, idx[0] = -1 (window = whole map).  Head dim 8, 16, 24 or 32 (equal in both branches); windows of up
+ *   to 288 tokens.
  * lepe_w[i] (Cb, 9) / lepe_b[i] (Cb) = get_v depthwise 3x3 weight/bias of branch i (:55).
  * y (B, L, C): x = softmax(scale q k^T) v + lepe, scattered by windows2img and concatenated (:98-107, :174).
+ * y0 (B, L, C) or NULL: the same without the lepe term (attn @ v of :103), in y's storage format.  Saved for the backward only:
+ *   rowsum(dO o y0) is the row term of the softmax gradient, so the backward neither recomputes LePE(v) nor reduces P o dP
+ *   across keys.  Pass NULL when no backward follows.
  * lse (B, sum(heads), L): row log-sum-exp saved for backward.  scale <= 0 selects head_dim^-0.5 (:42). */
-int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, float* y, float* lse,
+int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, float* y, float* y0, float* lse,
                    int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split, float scale,
                    float drop_p, unsigned long long drop_seed, int qkv_bf16, void* stream);
 /* drop_p in [0, 1) (0 = off): nn.Dropout on the attention probabilities (cswin_unet.py:101, attn_drop_rate): y = ((P o M) v) + lepe
@@ -68,16 +72,15 @@ int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* co
  * with the same (drop_p, drop_seed) regenerates the mask; the softmax statistics (lse) are those of the undropped P. */
 size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split);
 /* autograd backward of the above: dqkv (B, L, 3C), dlepe_w[i] (Cb, 9), dlepe_b[i] (Cb) are overwritten.
- * y (the forward output) and lepe_b are only read for windows of more than 112 tokens (384x384 inputs), where a
- * two-pass path replaces the fused kernel; they may be NULL otherwise.  The per-window partial slabs of the LePE conv
- * weight / bias gradient are reduced by one extra launch, or left in deferred[0..nbranch) for cswin_rows_sum_multi. */
+ * y0 = the forward's y0 output (NOT y).  The per-window partial slabs of the LePE conv weight / bias gradient are reduced by
+ * one extra launch, or left in deferred[0..nbranch) for cswin_rows_sum_multi. */
 int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, const float* lse,
-                   const float* y, const float* dy, float* dqkv, float* const* dlepe_w, float* const* dlepe_b,
+                   const float* y0, const float* dy, float* dqkv, float* const* dlepe_w, float* const* dlepe_b,
                    void* workspace, size_t ws_bytes, int B, int reso, int C, int nbranch, const int* heads, const int* idx,
                    int split, float scale, cswin_reduce_job* deferred, float drop_p, unsigned long long drop_seed, int qkv_bf16,
                    void* stream);
 /* qkv_bf16: storage mode of both attention entry points.  0: every tensor fp32.  1: qkv (and dqkv) are STORED as bf16 -- the
- * output format of cswin_linear_fwd(io_bf16 bit 1).  3: additionally y (the forward output, re-read by the backward) is stored
+ * output format of cswin_linear_fwd(io_bf16 bit 1).  3: additionally y and y0 (the forward outputs) are stored
  * as bf16 -- the input format of the proj Linear's io_bf16 bit 0.  In modes 0 - 3 the arithmetic of the attention kernels is
  * fp32 throughout (v_mfma_f32_16x16x4_f32).  7: mode 3 with bf16 MATRIX instructions (v_mfma_f32_16x16x32_bf16 for QK^T and
  * dO V^T, v_mfma_f32_16x16x16_bf16 for P V, dV, dK, dQ): operands (scaled q, k, v, P, dS, dO) are rounded to bf16 on their way

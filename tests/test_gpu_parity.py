@@ -1026,12 +1026,14 @@ def test_attention_bf16_y_storage_bit_exact(reso, idx, split, dim, heads):
     ha, ia = _int_array([nh]), _int_array([idx])
     E = lambda *sh, dt=torch.float32: torch.empty(*sh, dtype=dt, device=DEV)
     y32, y16, lse32, lse16 = E(B, L, C), E(B, L, C, dt=torch.bfloat16), E(B, nh, L), E(B, nh, L)
-    call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y32), ptr(lse32), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, 1, stream())
-    call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y16), ptr(lse16), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, 3, stream())
+    z32, z16 = E(B, L, C), E(B, L, C, dt=torch.bfloat16)          # y0 = P V, the output without the LePE term (the backward's input)
+    call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y32), ptr(z32), ptr(lse32), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, 1, stream())
+    call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y16), ptr(z16), ptr(lse16), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, 3, stream())
     assert bool((y16.view(torch.int16) == y32.bfloat16().view(torch.int16)).all()) and bool((lse16 == lse32).all())
+    assert bool((z16.view(torch.int16) == z32.bfloat16().view(torch.int16)).all())
     nbytes = lib().cswin_attn_bwd_workspace(B, reso, C, 1, ha, ia, split)
     res = []
-    for mode, y in ((1, y16.float()), (3, y16)):
+    for mode, y in ((1, z16.float()), (3, z16)):
         dq, dw_, db_, ws = E(B, L, 3 * C, dt=torch.bfloat16), E(C, 9), E(C), E(nbytes // 4 + 4)
         call("cswin_attn_bwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(lse32), ptr(y), ptr(dy), ptr(dq), _ptr_array([dw_]),
              _ptr_array([db_]), ptr(ws), nbytes, B, reso, C, 1, ha, ia, split, 0.0, None, 0.0, 0, mode, stream())
@@ -1041,7 +1043,7 @@ def test_attention_bf16_y_storage_bit_exact(reso, idx, split, dim, heads):
     assert bool((a.view(torch.int16) == d.view(torch.int16)).all()) and bool((b == e).all()) and bool((c == f).all())
     from cswin_unet_amd._lib import CswinHipError
     with pytest.raises(CswinHipError):
-        call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y16), ptr(lse16), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, 2, stream())
+        call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y16), ptr(z16), ptr(lse16), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, 2, stream())
 
 
 @pytest.mark.parametrize("reso,idx,split,dim,heads", [(56, 0, 1, 64, 2), (28, 1, 2, 128, 4), (14, 0, 7, 256, 8), (7, -1, 7, 512, 16),
@@ -1067,10 +1069,10 @@ def test_attention_bf16_matrix_instructions_vs_fp32(reso, idx, split, dim, heads
     nbytes = lib().cswin_attn_bwd_workspace(B, reso, C, 1, ha, ia, split)
     res = {}
     for mode in (3, 7):
-        y, lse = E(B, L, C, dt=torch.bfloat16), E(B, nh, L)
-        call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y), ptr(lse), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, mode, stream())
+        y, z, lse = E(B, L, C, dt=torch.bfloat16), E(B, L, C, dt=torch.bfloat16), E(B, nh, L)
+        call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y), ptr(z), ptr(lse), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, mode, stream())
         dq, dw_, db_, ws = E(B, L, 3 * C, dt=torch.bfloat16), E(C, 9), E(C), E(nbytes // 4 + 4)
-        call("cswin_attn_bwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(lse), ptr(y), ptr(dy), ptr(dq), _ptr_array([dw_]),
+        call("cswin_attn_bwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(lse), ptr(z), ptr(dy), ptr(dq), _ptr_array([dw_]),
              _ptr_array([db_]), ptr(ws), nbytes, B, reso, C, 1, ha, ia, split, 0.0, None, 0.0, 0, mode, stream())
         torch.cuda.synchronize()
         res[mode] = (y.float(), lse, dq.float(), dw_, db_)
@@ -1340,10 +1342,11 @@ def test_attention_probability_dropout(ops, reso, idx, split, dim, heads):
     E = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=DEV)
     nbytes = lib().cswin_attn_bwd_workspace(B, reso, C, 1, ha, ia, split)
 
-    def fwd(qkv, lw, lb, p, sd):
-        y, lse = E(B, L, C), E(B, nh, L)
-        call("cswin_attn_fwd", ptr(qkv), _ptr_array([lw]), _ptr_array([lb]), ptr(y), ptr(lse), B, reso, C, 1, ha, ia, split, 0.0, p, sd, 0, stream())
-        return y, lse
+    def fwd(qkv, lw, lb, p, sd, want_y0=False):
+        y, z, lse = E(B, L, C), E(B, L, C), E(B, nh, L)
+        call("cswin_attn_fwd", ptr(qkv), _ptr_array([lw]), _ptr_array([lb]), ptr(y), ptr(z) if want_y0 else None, ptr(lse), B, reso, C, 1, ha, ia,
+             split, 0.0, p, sd, 0, stream())
+        return (y, lse, z) if want_y0 else (y, lse)
 
     # statistics
     qkv = torch.zeros(B, L, 3 * C, device=DEV)
@@ -1361,9 +1364,9 @@ def test_attention_probability_dropout(ops, reso, idx, split, dim, heads):
     qkv = T(det_normal(f"adrop.{reso}.qkv", (B, L, 3 * C)) * 0.7)
     lw, lb = T(det_normal(f"adrop.{reso}.lw", (C, 9)) * 0.3), T(det_normal(f"adrop.{reso}.lb", (C,)) * 0.1)
     dy, d = T(det_normal(f"adrop.{reso}.dy", (B, L, C))), T(det_normal(f"adrop.{reso}.dir", (B, L, 3 * C)))
-    y, lse = fwd(qkv, lw, lb, p_drop, seed)
+    y, lse, z = fwd(qkv, lw, lb, p_drop, seed, want_y0=True)
     dq, dw_, db_, ws = E(B, L, 3 * C), E(C, 9), E(C), E(nbytes // 4 + 4)
-    call("cswin_attn_bwd", ptr(qkv), _ptr_array([lw]), _ptr_array([lb]), ptr(lse), ptr(y), ptr(dy), ptr(dq), _ptr_array([dw_]),
+    call("cswin_attn_bwd", ptr(qkv), _ptr_array([lw]), _ptr_array([lb]), ptr(lse), ptr(z), ptr(dy), ptr(dq), _ptr_array([dw_]),
          _ptr_array([db_]), ptr(ws), nbytes, B, reso, C, 1, ha, ia, split, 0.0, None, p_drop, seed, 0, stream())
     eps = 1e-2
     yp, _ = fwd(qkv + eps * d, lw, lb, p_drop, seed)

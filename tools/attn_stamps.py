@@ -12,26 +12,33 @@ idx = [-1] if single else [0, 1]; hb = [heads[si]] if single else [heads[si] // 
 nb, cb = len(idx), C // len(idx)
 dev = "cuda"
 qkv = torch.randn(batch, L, 3 * C, device=dev); w = [torch.randn(cb, 9, device=dev) / 3 for _ in idx]; b = [torch.randn(cb, device=dev) * .02 for _ in idx]
-dy = torch.randn(batch, L, C, device=dev); y = torch.empty(batch, L, C, device=dev); lse = torch.empty(batch, sum(hb), L, device=dev)
+dy = torch.randn(batch, L, C, device=dev); y = torch.empty(batch, L, C, device=dev); y0 = torch.empty_like(y); lse = torch.empty(batch, sum(hb), L, device=dev)
 dqkv = torch.empty_like(qkv); dw = [torch.empty_like(t) for t in w]; db = [torch.empty_like(t) for t in b]
 ia, ha = (ctypes.c_int * nb)(*idx), (ctypes.c_int * nb)(*hb)
 pa = lambda ts: (ctypes.c_void_p * nb)(*[t.data_ptr() for t in ts])
 nbytes = lib().cswin_attn_bwd_workspace(batch, reso, C, nb, ha, ia, split[si]); ws = torch.empty(nbytes // 4 + 4, device=dev)
-call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(lse), batch, reso, C, nb, ha, ia, split[si], 0.0, 0.0, 0, 0, stream())
-def bwd(): call("cswin_attn_bwd", ptr(qkv), pa(w), pa(b), ptr(lse), ptr(y), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws), nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, None, 0.0, 0, 0, stream())
+call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(y0), ptr(lse), batch, reso, C, nb, ha, ia, split[si], 0.0, 0.0, 0, 0, stream())
+def bwd(): call("cswin_attn_bwd", ptr(qkv), pa(w), pa(b), ptr(lse), ptr(y0), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws), nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, None, 0.0, 0, 0, stream())
 for _ in range(3): bwd()
 torch.cuda.synchronize()
 st = torch.zeros(1 << 16, 8, dtype=torch.int64, device=dev)
 h = lib(); h.cswin_debug_set_attn_stamps.argtypes = [ctypes.c_void_p]
-def fwd(): call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(lse), batch, reso, C, nb, ha, ia, split[si], 0.0, 0.0, 0, 0, stream())
+def fwd(): call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(y0), ptr(lse), batch, reso, C, nb, ha, ia, split[si], 0.0, 0.0, 0, 0, stream())
 h.cswin_debug_set_attn_stamps(ctypes.c_void_p(st.data_ptr())); (fwd if FWD else bwd)(); torch.cuda.synchronize(); h.cswin_debug_set_attn_stamps(None)
 s = st.cpu().numpy(); s = s[s[:, 0] != 0]
 print(f"stage {si+1}: {len(s)} workgroups")
-names = ["P0 load -> LDS", "P1 delta + LePE wgrad", "P2 fused loop + dK/dV", "barrier + K image", "P3 dQ", "slab store"]
-if FWD: names = ["K/V -> LDS", "S + softmax (tile 0)", "PV (tile 0)", "LePE + store (+ more tiles)"]
+OLD = os.environ.get("CSWIN_ATTN_OLD", "0") == "1"
+if OLD:
+    names = ["P0 load -> LDS", "P1 delta + LePE wgrad", "P2 fused loop + dK/dV", "barrier + K image", "P3 dQ", "slab store"]
+    if FWD: names = ["K/V -> LDS", "S + softmax (tile 0)", "PV (tile 0)", "LePE + store (+ more tiles)"]
+else:       # persistent kernels: phases of a workgroup's FIRST item, then its whole life (slot 7)
+    names = ["A stage + delta, barrier", "issue next, V fragments", "B LePE wgrad", "barrier, C fused loop, dK/dV", "barrier, K image, barrier", "D dQ"]
+    if FWD: names = ["K -> LDS, barrier", "S + softmax", "V -> LDS, barrier, PV", "LePE + store"]
 for k, nm in enumerate(names):
     d = s[:, k + 1] - s[:, k]
-    print(f"  {nm:24s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f} shader cycles (s_memtime)")
-E = 4 if FWD else 6
-d = s[:, E] - s[:, 0]; print(f"  {'total':24s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f}")
-d = s[:, E].max() - s[:, 0].min(); print(f"  kernel span {d} cycles")
+    print(f"  {nm:28s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f} shader cycles (s_memtime)")
+E = len(names)
+d = s[:, E] - s[:, 0]; print(f"  {'first item':28s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f}")
+if not OLD:
+    d = s[:, 7] - s[:, 0]; print(f"  {'workgroup life':28s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f} max {d.max():8.0f}")
+    d = s[:, 7] - s[:, E]; print(f"  {'after the first item':28s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f} max {d.max():8.0f}")
