@@ -110,18 +110,18 @@ def attention_roofline(batch, cfg, img_size=224, bf16=False):
     # HBM bytes of the same 52 launches from PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
     # FETCH_SIZE doubled per MI355X_MICROARCH.md; tools/attn_pmc.sh -> profiles/round2_attn_pmc.json).  Only valid for
     # the profiled configuration (224x224, batch 24).
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "round2_attn_pmc.json")
-    if not os.path.exists(pmc):
-        pmc = os.path.join(ROOT, "profiles", "round1_attn_pmc.json")
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "round3_attn_pmc.json")
     if batch == 24 and img_size == 224 and os.path.exists(pmc) and not bf16:
         per = json.load(open(pmc))["per_launch"]
         traffic = int(sum(2 * depth[si] * (per[f"stage{si + 1}"]["fwd_bytes"] + per[f"stage{si + 1}"]["bwd_bytes"]) for si in range(4)))
-    return {"kernel": "attn_fwd_kernel + attn_bwd_kernel / attn_bwd2_kernel (+ their slab reduction launch), all 26 blocks of one step", "bound": "mfma",
+        traffic_src = "STORED profile profiles/round3_attn_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of these kernels, tools/attn_pmc.sh), not measured in this run"
+    return {"kernel": "attn_fwd3_kernel + attn_bwd3_kernel (+ the slab reduction launch of the LePE gradients), all 26 blocks of one step", "bound": "mfma",
             "achieved": round(achieved, 2), "peak": PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / (PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS), 4), "traffic": traffic,
             "matrix_instructions": "bf16 (v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16), fp32 accumulate" if bf16 else "fp32 (v_mfma_f32_16x16x4_f32)",
-            "traffic_note": "bytes per step (52 launches); algorithmic bytes per step = %d" % int(tot_bytes),
+            "traffic_note": "bytes per step (52 launches); algorithmic bytes per step = %d (q, k, v, dy in / y, dqkv out; the kernels also write and re-read y0 = P V, 8 L C more per block and image)" % int(tot_bytes),
+            "traffic_source": traffic_src,
             "algorithmic_gflop_per_step": round(tot_flops / 1e9, 2), "time_per_step_ms": round(tot_time * 1e3, 3),
             "hbm_frac_algorithmic": round(tot_bytes / tot_time / 1e9 / PEAK_HBM_GBPS, 4), "per_stage": rows}
 
@@ -156,8 +156,7 @@ def gemm_family_roofline(batch, cfg, img_size=224):
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
             "algorithmic_gflop_per_step": round(tot_f / 1e9, 1), "time_per_step_ms": round(tot_t * 1e3, 3),
-            "sustained_mfma_tflops_measured": 141.0,
-            "note": "peak is the 2.4 GHz data-sheet figure; tools/micro/mfma_peak.hip (MFMAs only, no memory) sustains 137-146 TFLOP/s on this chip"}
+            "note": "peak is the 2.4 GHz data-sheet figure; an MFMA-only probe (tools/micro/mfma_peak.hip, profiles/round1_notes.md) sustained 137-146 TFLOP/s on this chip in round 1 -- not re-measured in this run"}
 
 def cpu_baseline(batch, steps=2):
     """The CPU oracle's training step (same model, loss, optimiser, synthetic batch) on the host cores."""
@@ -224,6 +223,73 @@ def _spawn_ranks(n, argv):
     return rc
 
 
+def _timed_steps(trainer, img, lab, steps, warmup, world, dev):
+    """2 set-up steps (eager warm-up + hipGraph capture), `warmup` untimed steps, then EXACTLY `steps` steps between barrier +
+    synchronize on both sides (wall clock, MAX over ranks).  Every timed step is also bracketed by HIP events on the trainer's
+    stream: their per-step times give the median the survey asks for (8d) next to the mean the driver's contract defines."""
+    for _ in range(2):
+        trainer.train_step(img, lab)
+    for _ in range(warmup):
+        trainer.train_step(img, lab)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ev[i].record()
+        stats = trainer.train_step(img, lab)
+    ev[steps].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    return elapsed, step_ms, stats
+
+
+def _median(v):
+    n = len(v)
+    return 0.5 * (v[(n - 1) // 2] + v[n // 2])
+
+
+def bf16_mode_line(args, config, num_classes, dev):
+    """BASELINE configs[2]'s per-GPU workload (same model, batch and step; bf16 MFMA for every Linear / conv and the attention
+    products, bf16 block activations and weight shadow, fp32 accumulation / residual stream / statistics / master weights) for 20
+    timed steps, after the fp32 headline has been measured: an extra key of the fp32 line, not a headline of its own."""
+    import cswin_unet_amd
+    from cswin_unet_amd.networks.vision_transformer import CSwinUnet
+    from cswin_unet_amd.trainer import DataParallelTrainer, synthetic_batch
+    prev = cswin_unet_amd.set_matmul_precision("bf16")
+    try:
+        torch.manual_seed(1234)
+        model = CSwinUnet(config, img_size=config.DATA.IMG_SIZE, num_classes=num_classes).to(dev)
+        model.train()
+        trainer = DataParallelTrainer(model, num_classes, base_lr=0.05, max_iterations=1000, group=None, use_graph=not args.no_graph,
+                                      allreduce_dtype=torch.bfloat16)
+        img, lab = synthetic_batch(args.batch, config.DATA.IMG_SIZE, num_classes, 1234, dev)
+        steps = 20
+        elapsed, step_ms, stats = _timed_steps(trainer, img, lab, steps, 5, 1, dev)
+        loss = [float(v) for v in stats.tolist()]
+        out = {"workload": "BASELINE configs[2] per GPU: cswin_tiny_224_lite, synthetic 224x224 9-class, bs=%d, bf16" % args.batch,
+               "dtype": "bf16 GEMM / attention operands + bf16 block activations / weight shadow, f32 accumulate, residual stream, statistics, master weights",
+               "steps": steps, "warmup": 5, "ms_per_step": round(elapsed / steps * 1e3, 3), "ms_per_step_median": round(_median(step_ms), 3),
+               "value": round(args.batch * steps / elapsed, 2), "unit": "images/sec",
+               "final_loss": {"loss": round(loss[0], 5), "ce": round(loss[1], 5), "dice": round(loss[2], 5)}}
+        if not args.skip_roofline:
+            out["roofline"] = attention_roofline(args.batch, config.MODEL.CSWIN, config.DATA.IMG_SIZE, bf16=True)
+        del trainer, model
+        return out
+    finally:
+        cswin_unet_amd.set_matmul_precision(prev)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -234,6 +300,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying hipGraphs")
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-bf16", action="store_true", help="do not append the bf16-mode measurement to the fp32 headline line")
     ap.add_argument("--cpu-batch", type=int, default=24)
     ap.add_argument("--matmul", choices=["fp32", "bf16"], default="fp32",
                     help="fp32: exact fp32 MFMA (BASELINE configs[1], the default and the headline); bf16 (configs[2..4]): bf16 MFMA "
@@ -277,26 +344,7 @@ def main():
     img, lab = synthetic_batch(args.batch, config.DATA.IMG_SIZE, num_classes, 1234 + rank, dev)
 
     log(f"[bench] rank {rank}/{world}: model built, capturing ...")
-    for _ in range(2):                      # set-up steps (eager warm-up + hipGraph capture happen in the first), not part of W
-        trainer.train_step(img, lab)
-    for _ in range(args.warmup):
-        trainer.train_step(img, lab)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        stats = trainer.train_step(img, lab)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, step_ms, stats = _timed_steps(trainer, img, lab, args.steps, args.warmup, world, dev)
     loss = [float(v) for v in stats.tolist()]
     log(f"[bench] timed region done: {elapsed / args.steps * 1e3:.3f} ms/step")
 
@@ -308,7 +356,7 @@ def main():
             f"training images/sec ({config.DATA.IMG_SIZE}x{config.DATA.IMG_SIZE}, {name}) [not the headline configuration]"
         out = {"metric": metric, "value": round(world * args.batch * args.steps / elapsed, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": round(ms, 3), "ms_per_step_median": round(_median(step_ms), 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if args.matmul == "fp32" else "bf16 GEMM operands + bf16 block activations / weight shadow, f32 accumulate, residual stream, attention math, master weights", "data": "synthetic",
                "config": {"workload": f"{os.path.splitext(os.path.basename(args.cfg))[0]}, synthetic {config.DATA.IMG_SIZE}x{config.DATA.IMG_SIZE} 9-class, "
                                       f"bs={args.batch}/GPU, {args.matmul} matmul, "
@@ -323,6 +371,10 @@ def main():
             if args.matmul == "fp32":
                 log("[bench] GEMM family roofline sub-benchmark ...")
                 out["roofline_dominant_by_time"] = gemm_family_roofline(args.batch, config.MODEL.CSWIN, config.DATA.IMG_SIZE)
+        if world == 1 and headline and args.matmul == "fp32" and not args.skip_bf16:
+            log("[bench] bf16 mode (BASELINE configs[2] per-GPU workload), 20 steps ...")
+            del trainer
+            out["bf16_mode"] = bf16_mode_line(args, config, num_classes, dev)
         if world == 1 and not args.skip_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
         print(json.dumps(out), flush=True)

@@ -23,9 +23,12 @@ def set_matmul_precision(mode):
 
 
 def set_activation_storage(dtype):
-    """"bf16" (default) or "fp32": how a CSWinBlock stores qkv, the MLP hidden activations and their gradients WHEN the matmul
-    precision is bf16 (with fp32 matmuls storage is always fp32).  The residual stream, LayerNorm outputs, statistics, master
-    weights and all accumulation stay fp32 either way.  Returns the previous setting."""
+    """"bf16" (default) or "fp32": how a CSWinBlock stores its GEMM-only tensors WHEN the matmul precision is bf16 (with fp32
+    matmuls storage is always fp32).  Stored as bf16: both LayerNorm outputs, qkv, the attention outputs (y and y0), the MLP hidden
+    pair (pre-activation and activation) and, in backward, dqkv, the hidden gradient and the rounded twins of the residual-stream
+    gradients that the GEMMs read.  Kept in fp32 either way: the residual stream and its gradients, LayerNorm and softmax
+    statistics, attention arithmetic other than the bf16 matrix products, master weights, momentum and every accumulation.
+    Returns the previous setting."""
     from . import _lib
     if dtype not in ("bf16", "fp32"):
         raise ValueError(f"activation storage {dtype!r}: expected 'bf16' or 'fp32'")

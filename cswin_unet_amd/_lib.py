@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libcswin_hip.so")
 
 P, I, F, SZ, L, D = c_void_p, c_int, c_float, c_size_t, c_long, c_double
 
+ABI_VERSION = 3          # CSWIN_ABI_VERSION of the include/cswin_hip.h this table mirrors; lib() refuses any other library
+
 # name -> (restype, argtypes); mirrors include/cswin_hip.h one to one (tests/test_abi.py checks both ways)
 SIGNATURES = {
     "cswin_last_error": (c_char_p, []),
@@ -138,6 +140,21 @@ def shadow_ptr(w):
     return None
 
 
+def shadows_current(opt):
+    """Re-pack `opt`'s bf16 shadow if any of its parameters changed version since the shadow was last known to match (one host
+    loop over the parameters; called before a captured step is replayed, which consults no Python otherwise).  Raw writes to
+    opt.flat_param (not through a parameter) move no version counter: follow them with opt.refresh_shadow() yourself."""
+    if _state["precision"] != PREC_BF16:
+        return
+    for e in _shadows:
+        if e.ref() is opt:
+            if any(e.seen.get(p.data_ptr()) != p._version for p in opt.params):
+                opt.refresh_shadow()
+                e.seen.clear()
+                e.seen.update({p.data_ptr(): p._version for p in opt.params})
+            return
+
+
 def set_precision(mode):
     prev = _state["precision"]
     _state["precision"] = int(mode)
@@ -167,6 +184,10 @@ def lib():
             except AttributeError as e:
                 raise CswinHipError(f"{LIB_PATH} does not export {name}") from e
             fn.restype, fn.argtypes = res, args
+        have = handle.cswin_abi_version()
+        if have != ABI_VERSION:
+            raise CswinHipError(f"{LIB_PATH} was built for C ABI version {have}, this package binds version {ABI_VERSION}: rebuild it "
+                                f"(`make -C cswin_unet_amd/csrc`)")
         _lib = handle
     return _lib
 

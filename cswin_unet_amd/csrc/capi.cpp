@@ -18,7 +18,7 @@ extern "C" {
 
 const char* cswin_last_error(void) { return g_err; }
 
-int cswin_abi_version(void) { return 1; }
+int cswin_abi_version(void) { return CSWIN_ABI_VERSION; }
 
 // 1 if a gfx950 device is visible to the HIP runtime this library is bound to
 int cswin_device_ok(void) {

@@ -13,6 +13,8 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// bumped whenever a prototype of include/cswin_hip.h changes (the same constant is defined there; tests compare the two)
+#define CSWIN_ABI_VERSION 3
 #define CSWIN_OK 0
 #define CSWIN_ERR_SHAPE (-1)
 #define CSWIN_ERR_ALIGN (-2)
@@ -64,8 +66,8 @@ __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
     e = __expf(-u * u);
     const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float erf_abs = fmaf(-poly, e, 1.0f);
-    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+    const float tail = 0.5f * poly * e;                 // Phi(-|x|) = (1 - erf(|x| / sqrt 2)) / 2: formed directly, so the negative tail
+    cdf = x < 0.f ? tail : 1.0f - tail;                 // keeps its relative accuracy (1 - (1 - tail) cancels at fp32 epsilon)
 }
 __device__ __forceinline__ float gelu_f(float x) {
     float cdf, e;

@@ -77,7 +77,9 @@ __global__ void loss_finalize_kernel(const float* __restrict__ sums, float* __re
         coef[ncls + c] = wc * 2.f * (2.f * I + smooth) / (D * D);
     }
     dice /= ncls;
-    out[0] = w_ce * ce + w_dice * dice;
+    // an out-of-range label poisons the CE sum (NaN); utils.DiceLoss (w_ce = 0) one-hots with == and simply ignores such a label
+    // (utils.py:13-19), so the CE term must not reach a loss that has none
+    out[0] = (w_ce != 0.f ? w_ce * ce : 0.f) + w_dice * dice;
     out[1] = ce;
     out[2] = dice;
 }

@@ -236,6 +236,10 @@ class HipEngine:
             if img.data_ptr() != self._img.data_ptr():
                 self._img.copy_(img)
                 self._lab.copy_(lab)
+            # a replay runs no Python: a weight written from outside the step (load_state_dict, load_from, copy_ on a parameter)
+            # since the last one is noticed here by its version counter and answered with one re-pack of the bf16 shadow
+            from ._lib import shadows_current
+            shadows_current(self.opt)
             self._graphs[0].replay()
         else:
             self._logits = self._forward_sums(img, lab)

@@ -26,6 +26,11 @@
 extern "C" {
 #endif
 
+/* Bumped whenever a prototype or struct below changes (1: round 1; 2: round 2 -- stream / precision / storage arguments; 3: round 3 --
+ * cswin_attn_fwd writes y0, cswin_attn_bwd reads it).  cswin_abi_version() returns the value the library was built with: a consumer
+ * compiled against another header must refuse to call it. */
+#define CSWIN_ABI_VERSION 3
+
 #define CSWIN_OK 0
 #define CSWIN_ERR_SHAPE (-1)
 #define CSWIN_ERR_ALIGN (-2)

@@ -54,7 +54,7 @@ def ops():
 def test_library_is_the_hip_one():
     from cswin_unet_amd import _lib
     h = _lib.lib()
-    assert h.cswin_abi_version() == 1
+    assert h.cswin_abi_version() == 3
     assert h.cswin_device_ok() == 1, h.cswin_last_error().decode()
     with pytest.raises(_lib.CswinHipError):         # no CPU fallback
         from cswin_unet_amd import ops
@@ -1246,6 +1246,61 @@ def test_out_of_range_label_poisons_the_loss(ops):
     lab[1, 3, 5] = 255
     loss, _ = ops.ce_dice_loss(logits, T(lab))
     assert torch.isnan(loss)
+
+
+def test_dice_loss_ignores_an_out_of_range_label():
+    """The reference DiceLoss one-hots with == (utils.py:13-19): a label outside [0, n_classes) matches no class and is simply
+    ignored.  The fused kernels poison the CE sum for such a label; a loss without a CE term (utils.DiceLoss: w_ce = 0) must not
+    inherit that NaN, in value or in gradient."""
+    from cswin_unet_amd.utils import DiceLoss
+    ncls = 4
+    logits = det_normal("diceoor.logits", (2, ncls, 24, 24))
+    lab = det_labels("diceoor.lab", (2, 24, 24), ncls).copy()
+    lab[0, 3, 5] = 255
+    lab[1, 0, 0] = ncls
+
+    def restated(lg, target):
+        pr = torch.softmax(lg, 1)
+        loss = 0.0
+        for c in range(ncls):
+            t = (target == c).float()
+            loss = loss + (1 - (2 * (pr[:, c] * t).sum() + 1e-5) / ((pr[:, c] ** 2).sum() + (t * t).sum() + 1e-5))
+        return loss / ncls
+    lg = T(logits, grad=True)
+    loss = DiceLoss(ncls)(lg, T(lab), softmax=True)
+    loss.backward()
+    ref_in = torch.from_numpy(logits).requires_grad_()
+    ref = restated(ref_in, torch.from_numpy(lab))
+    ref.backward()
+    assert torch.isfinite(loss) and abs(float(loss) - float(ref)) < 1e-5
+    rel_err(lg.grad, ref_in.grad, "diceoor.dlogits")
+
+
+def test_graph_replay_sees_weights_written_from_outside(N, bf16_matmul):
+    """A captured step has the bf16 weight shadow's address baked in and runs no Python when replayed: a weight written from
+    outside the step (load_state_dict / copy_ on a parameter) must reach the shadow before the next replay.  The first loss after
+    such a write has to be the loss of the NEW weights (checked against a fresh eager trainer on the same weights)."""
+    from cswin_unet_amd.trainer import DataParallelTrainer
+    mk = lambda: fill_state_dict(N.CSWinTransformer(img_size=224, num_classes=9, embed_dim=64, depth=[1, 1, 1, 1], split_size=[1, 2, 7, 7],
+                                                    num_heads=[2, 4, 8, 16], qkv_bias=True, drop_path_rate=0.).to(DEV)).train()
+    img = T(det_normal("stale.x", (2, 1, 224, 224))).repeat(1, 3, 1, 1)
+    lab = T(det_labels("stale.labels", (2, 224, 224), 9))
+    net = mk()
+    tr = DataParallelTrainer(net, 9, base_lr=0.0, max_iterations=100, use_graph=True)      # lr 0: the steps leave the weights alone
+    l0 = float(tr.train_step(img, lab)[0])
+    assert abs(float(tr.train_step(img, lab)[0]) - l0) < 1e-6 * abs(l0)
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if n_.endswith("qkv.weight") or n_.endswith("fc1.weight"):
+                p_.copy_(p_ * 1.5)
+    l1 = float(tr.train_step(img, lab)[0])                         # replayed graph, new weights
+    net2 = mk()
+    with torch.no_grad():
+        for (n_, p_), (_, q_) in zip(net2.named_parameters(), net.named_parameters()):
+            p_.copy_(q_)
+    l2 = float(DataParallelTrainer(net2, 9, base_lr=0.0, max_iterations=100, use_graph=False).train_step(img, lab)[0])
+    assert abs(l1 - l0) > 1e-4 * abs(l0), "the write did not change the loss: the test does not see the shadow"
+    assert abs(l1 - l2) < 2e-4 * abs(l2), (l0, l1, l2)
 
 
 def test_bf16_wire_pack_unpack():
