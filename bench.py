@@ -347,6 +347,15 @@ def main():
     elapsed, step_ms, stats = _timed_steps(trainer, img, lab, args.steps, args.warmup, world, dev)
     loss = [float(v) for v in stats.tolist()]
     log(f"[bench] timed region done: {elapsed / args.steps * 1e3:.3f} ms/step")
+    dp_diag = None
+    if world > 1:
+        # outside the timed region: five more steps with a HIP event after every backward phase, around the wait for the
+        # collectives and after the update, so that one multi-GPU run says where its time went (rank 0's view)
+        trainer.enable_timing()
+        for _ in range(5):
+            trainer.train_step(img, lab)
+        dp_diag = trainer.collect_timing()
+        trainer.enable_timing(False)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -365,6 +374,11 @@ def main():
                           "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
                "final_loss": {"loss": round(loss[0], 5), "ce": round(loss[1], 5), "dice": round(loss[2], 5)},
                "model_tflops": round(33.2e9 * world * args.batch * args.steps / elapsed / 1e12, 2) if config.DATA.IMG_SIZE == 224 and config.MODEL.CSWIN.EMBED_DIM == 64 else None}
+        if dp_diag is not None:
+            dp_diag["note"] = ("mean ms over 5 instrumented steps after the timed region (rank 0): per backward phase (loss + decoder | deep encoder | "
+                               "shallow encoder; each phase's gradient buckets go on the wire when it ends), the time the compute stream then "
+                               "waited for the collectives (+ bf16 unpack), and the SGD update")
+            out["dp_diagnostics"] = dp_diag
         if world == 1 and not args.skip_roofline:
             log("[bench] attention roofline sub-benchmark ...")
             out["roofline"] = attention_roofline(args.batch, config.MODEL.CSWIN, config.DATA.IMG_SIZE, bf16=args.matmul == "bf16")

@@ -56,6 +56,7 @@ SIGNATURES = {
     "cswin_sgd_flat": (I, [P, P, P, L, P, F, F, F, P, P]),
     "cswin_multi_copy": (I, [P, I, P]),
     "cswin_pack_bf16": (I, [P, P, L, P]),
+    "cswin_pack_bf16_scaled": (I, [P, P, L, F, P]),
     "cswin_unpack_bf16": (I, [P, P, L, P]),
 }
 

@@ -66,8 +66,11 @@ __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
     e = __expf(-u * u);
     const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float tail = 0.5f * poly * e;                 // Phi(-|x|) = (1 - erf(|x| / sqrt 2)) / 2: formed directly, so the negative tail
-    cdf = x < 0.f ? tail : 1.0f - tail;                 // keeps its relative accuracy (1 - (1 - tail) cancels at fp32 epsilon)
+    // Phi(-|x|) = (1 - erf(|x| / sqrt 2)) / 2 = poly e / 2 is formed directly, so the negative tail keeps its relative accuracy
+    // (1 - (1 - tail) cancels at fp32 epsilon).  Explicit fmaf: under -ffp-contract=fast the compiler would otherwise contract
+    // 1 - tail in some instantiations and not in others, and the storage variants of one epilogue must agree bit for bit.
+    const float pe = poly * e;
+    cdf = x < 0.f ? 0.5f * pe : fmaf(-0.5f, pe, 1.0f);
 }
 __device__ __forceinline__ float gelu_f(float x) {
     float cdf, e;

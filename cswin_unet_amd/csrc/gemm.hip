@@ -24,8 +24,6 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 
-// wsgemm.hip: weight-stationary family for plain tall-skinny Linears (returns 1 when the shape is not served there)
-int cswin_ws_gemm(int mode, int epi_mode, const float* A, const float* W, const void* epilogue, int M, int N, int R, void* stream);
 // both operands stored as bf16 (gemm16.hip); 0 = launched, 1 = not covered
 int cswin_gemm16(int mode, int epi_mode, const void* A, const void* B, const void* epilogue, int M, int NO, int R, void* stream);
 // wgrad16.hip: bf16-operand weight gradients with transposing LDS reads (bf16 matmul mode)
@@ -708,14 +706,6 @@ int cswin_linear_fwd(const float* x, const float* x2, int k_split, const float* 
             else launch_gemm<true, true, 1, EPI_PLAIN, false>(A, B, e, M, N, K, 1, rk, precision, st);
         }
     } else {
-        if (precision == 0) {
-            const int rc = cswin_ws_gemm(0, y_act ? EPI_ACT : (residual ? EPI_RES : EPI_PLAIN), x, w, &e, M, N, K, stream);
-            if (rc < 0) return rc;
-            if (rc == 0) {
-                CSWIN_LAUNCH_CHECK();
-                return CSWIN_OK;
-            }
-        }
         if (precision == 1 && (io_bf16 & 5) == 5) {             // both operands stored as bf16: LDS-DMA kernel (gemm16.hip)
             if (cswin_gemm16(0, y_act ? EPI_ACT : (residual ? EPI_RES : EPI_PLAIN), x, w, &e, M, N, K, stream) == 0) {
                 CSWIN_LAUNCH_CHECK();
@@ -768,14 +758,6 @@ int cswin_linear_bwd_data(const float* dy, const float* w, float* dx, float* dx2
     const int rn = cdiv(N, BKMAX) * BKMAX;
     const int modes = (dx2 != nullptr) + (gelu_pre != nullptr) + (add != nullptr);
     CSWIN_REQUIRE(modes <= 1, CSWIN_ERR_UNSUPPORTED, "linear_bwd_data: dx2 / gelu_pre / add are mutually exclusive");
-    if (!dx2 && precision == 0) {
-        const int rc = cswin_ws_gemm(1, gelu_pre ? EPI_GELUBWD : (add ? EPI_RES : EPI_PLAIN), dy, w, &e, M, K, N, stream);
-        if (rc < 0) return rc;
-        if (rc == 0) {
-            CSWIN_LAUNCH_CHECK();
-            return CSWIN_OK;
-        }
-    }
     if (precision == 1 && !dx2 && !add && (io_bf16 & 5) == 5) {  // both operands stored as bf16: LDS-DMA kernel (gemm16.hip)
         if (cswin_gemm16(1, gelu_pre ? EPI_GELUBWD : EPI_PLAIN, dy, w, &e, M, K, N, stream) == 0) {
             CSWIN_LAUNCH_CHECK();

@@ -55,18 +55,17 @@ template <int N> __device__ __forceinline__ void g16_wait() { asm volatile("s_wa
 __device__ __forceinline__ void g16_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // S: LDS stages = ring slots in flight (2 .. 4).  BT: data gradient (W rows run along the reduction index).
-// KG: k-groups.  KG = 2 (long reductions with about one workgroup per CU, where a workgroup's life IS the kernel time): eight
-// waves; wave group g takes the 64-k steps 2 i + g, a ring slot holds a PAIR of steps, the two accumulator sets meet in LDS
-// before the epilogue (run by group 0).  The loop is half as long for the same bytes and instructions.
+// (A two-k-group variant -- eight waves, alternate 64-k steps, accumulators meeting in LDS -- was shorter stand-alone on long
+// reductions and 0.06 ms slower in the step; removed in round 3, profiles/round2_notes.md.)
 // MODE 2: a 128 x 64 tile on eight waves (outputs with many tiles: half the workgroups to dispatch, the W tile shared by twice
 // the rows); a ring slot is the 16-KB A image + the 8-KB W image.
 template <int EPI, bool BT, int S, bool PRE16, int MODE>
 __global__ __launch_bounds__(MODE == 0 ? 256 : 512) void gemm16_kernel(G16Params p) {
-    constexpr int KG = MODE == 1 ? 2 : 1;            // k-groups
+    constexpr int KG = 1;                            // k-groups (one; see above)
     constexpr int TM = MODE == 2 ? 2 * G16_T : G16_T;  // tile rows
     extern __shared__ __attribute__((aligned(16))) unsigned char g16_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = MODE == 2 ? wave8 : (wave8 & 3), kgrp = MODE == 1 ? (wave8 >> 2) : 0;
+    const int wave = MODE == 2 ? wave8 : (wave8 & 3), kgrp = 0;
     const int li = lane & 31, lh = lane >> 5;
     constexpr int A_IMG = TM * 128;                  // bytes of the A image of a step
     constexpr int SLOT = KG * (A_IMG + G16_IMG);     // bytes of a ring slot
@@ -79,15 +78,15 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512) void gemm16_kernel(G16Params
     const int tail = p.R % G16_T;                    // 0, or 32 valid reduction values in the last step (KG = 1 only)
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)g16_lds;   // LDS byte address of the ring
 
-    // ---- DMA source addresses.  KG = 1: wave w moves row groups 2w and 2w + 1 (8 rows each) of both images of a step;
-    // KG = 2: wave w (0 .. 7) moves row group w of the four images of a pair of steps.  Four DMAs per wave and iteration.
+    // ---- DMA source addresses: wave w moves row groups 2w and 2w + 1 (8 rows each) of both images of a step (four DMAs per wave
+    // and iteration; the 128-row tile: three)
     const int drow = lane >> 3, slot = lane & 7;
     const unsigned char* a_src[2];
     const unsigned char* b_src[2];
     int a_td[2], b_td[2];                            // byte deltas of the sources for a half last step: stay inside the row / the matrix
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const int row = (KG == 2 ? wave8 : 2 * wave + g) * 8 + drow;     // row of the A image
+        const int row = (2 * wave + g) * 8 + drow;                       // row of the A image
         const int brow = MODE == 2 ? wave8 * 8 + drow : row;             // row of the W image (MODE 2: one group per wave)
         const int ca = slot ^ ((row >> 1) & 7);                          // source chunk of this lane's slot
         const int am = min(m0 + row, p.M - 1);                           // clamped rows are never stored
@@ -113,7 +112,7 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512) void gemm16_kernel(G16Params
             for (int g = 0; g < 2; ++g) g16_dma(a_src[g] + (long)it * (G16_T * 2) + (half ? a_td[g] : 0), st + (unsigned)wave8 * 2048 + g * 1024);
             const unsigned char* src = BT ? b_src[0] + (long)it * G16_T * p.ldb * 2 : b_src[0] + (long)it * (G16_T * 2);
             g16_dma(src + (half ? b_td[0] : 0), st + A_IMG + (unsigned)wave8 * 1024);
-        } else if constexpr (KG == 1) {
+        } else {
             const unsigned st = lds0 + (unsigned)(it % S) * SLOT + (unsigned)wave * 2048;
 #pragma unroll
             for (int g = 0; g < 2; ++g) g16_dma(a_src[g] + (long)it * (G16_T * 2) + (half ? a_td[g] : 0), st + g * 1024);
@@ -121,15 +120,6 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512) void gemm16_kernel(G16Params
             for (int g = 0; g < 2; ++g) {
                 const unsigned char* src = BT ? b_src[g] + (long)it * G16_T * p.ldb * 2 : b_src[g] + (long)it * (G16_T * 2);
                 g16_dma(src + (half ? b_td[g] : 0), st + G16_IMG + g * 1024);
-            }
-        } else {
-            const unsigned st = lds0 + (unsigned)(it % S) * SLOT + (unsigned)wave8 * 1024;
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {                                 // g = step of the pair (= the k-group that consumes it)
-                const long step = 2L * it + g;
-                g16_dma(a_src[0] + step * (G16_T * 2), st + g * G16_STAGE);
-                const unsigned char* src = BT ? b_src[0] + step * G16_T * p.ldb * 2 : b_src[0] + step * (G16_T * 2);
-                g16_dma(src, st + g * G16_STAGE + G16_IMG);
             }
         }
     };
@@ -209,17 +199,6 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512) void gemm16_kernel(G16Params
     // ---- epilogue (the vector path of gemm_epilogue.h's run_epilogue for one 32 x 32 fragment, operands already in registers):
     // C/D layout (lane = column, registers = rows) -> private [32][36] LDS patch -> lane owns 4 consecutive columns of 4 rows
     acc0 += acc1;
-    if constexpr (KG == 2) {                  // the second k-group's accumulators meet the first's through LDS (lane-contiguous patches)
-        float* xch = reinterpret_cast<float*>(g16_lds) + 4 * EP_WAVE_FLOATS + wave * 16 * 64;
-        if (kgrp == 1) {
-#pragma unroll
-            for (int g = 0; g < 16; ++g) xch[g * 64 + lane] = acc0[g];
-        }
-        __syncthreads();
-        if (kgrp == 1) return;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) acc0[g] += xch[g * 64 + lane];
-    }
     float* wbuf = reinterpret_cast<float*>(g16_lds) + wave * EP_WAVE_FLOATS;      // MODE 2: eight patches (wave = 0 .. 7)
 #pragma unroll
     for (int g = 0; g < 16; ++g) wbuf[((g & 3) + 8 * (g >> 2) + 4 * lh) * EP_LD + li] = acc0[g];
@@ -253,31 +232,20 @@ template <int EPI, bool BT, bool PRE16>
 int g16_launch(const G16Params& p, hipStream_t st) {
     const int nsteps = (p.R + G16_T - 1) / G16_T;
     const int forced = cswin_tuning().gemm16_stages;                                                        // tuning aid: 2 .. 4
-    const int forced_kg = cswin_tuning().gemm16_kg;                                                         // tuning aid: 1 / 2
-    // Two k-groups for long reductions with about one workgroup per CU: stand-alone the workgroup life drops (K = 1024: 13.5 k ->
-    // 11.3 k cycles, kernel span 10.0 -> 7.7 us), inside the step it does not pay (7.57 against 7.51 ms/step, twice each):
-    // opt-in only (CSWIN_GEMM16_KG=2 applies it where nsteps >= 8 and nblk <= 400).
-    const bool kg2 = forced_kg == 2 && nsteps >= 8 && nsteps % 2 == 0 && p.R % G16_T == 0 && p.nblk <= 400;
     const int forced_tm = cswin_tuning().gemm16_tm;                                                         // tuning aid: 64 / 128
-    const bool tm128 = !kg2 && (forced_tm == 128 || (forced_tm == 0 && p.nblk > 768));
+    const bool tm128 = forced_tm == 128 || (forced_tm == 0 && p.nblk > 768);
     int S = nsteps >= 3 ? 3 : 2;          // 48 KB: three workgroups per CU (measured against 2 and 4 stages: profiles/round2_notes.md)
     if (forced >= 2 && forced <= 4) S = forced;
     static_assert(2 * G16_STAGE >= 4 * EP_WAVE_FLOATS * (int)sizeof(float), "the smallest ring must hold the epilogue patches");
-    static_assert(4 * G16_STAGE >= (4 * EP_WAVE_FLOATS + 4 * 16 * 64) * (int)sizeof(float), "the two-k-group ring must hold the patches and the exchange");
     // dynamic-LDS opt-in of the instantiations: once per process, thread-safe (a function attribute, not a stream operation)
     static std::once_flag once;
     static hipError_t status = hipSuccess;
     std::call_once(once, [&] {
         status = hipFuncSetAttribute((const void*)gemm16_kernel<EPI, BT, 4, PRE16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G16_STAGE);
         if (status == hipSuccess) status = hipFuncSetAttribute((const void*)gemm16_kernel<EPI, BT, 3, PRE16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * G16_STAGE);
-        if (status == hipSuccess) status = hipFuncSetAttribute((const void*)gemm16_kernel<EPI, BT, 2, PRE16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G16_STAGE);
         if (status == hipSuccess) status = hipFuncSetAttribute((const void*)gemm16_kernel<EPI, BT, 3, PRE16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (3 * G16_IMG));
     });
     if (status != hipSuccess) return 1;
-    if (kg2) {                             // two ring slots of two steps each: 64 KB, two workgroups per CU
-        hipLaunchKernelGGL((gemm16_kernel<EPI, BT, 2, PRE16, 1>), dim3(p.nblk), dim3(512), 4 * G16_STAGE, st, p);
-        return 0;
-    }
     if (tm128) {                           // 128 x 64 tiles: three slots of 24 KB, two workgroups per CU
         G16Params q = p;
         q.tiles_m = cdiv(p.M, 2 * G16_T);

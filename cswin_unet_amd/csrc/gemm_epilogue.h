@@ -1,4 +1,4 @@
-// Epilogue shared by the GEMM kernels of libcswin_hip (gemm.hip: tiled family; wsgemm.hip: weight-stationary family).
+// Epilogue shared by the GEMM kernels of libcswin_hip (gemm.hip: tiled family; gemm16.hip: LDS-DMA bf16 kernel).
 #pragma once
 #include "common.h"
 

@@ -51,11 +51,11 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(const CopyChunk* __rest
 // v_cvt_pk_bf16_f32: NaN stays NaN) into a wire buffer that the collective sums, then widened back in place of the bucket.
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n) {
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n, float scale) {
     const long n4 = n / 4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
-        reinterpret_cast<bf16x4_t*>(dst)[i] = __builtin_convertvector(reinterpret_cast<const f32x4*>(src)[i], bf16x4_t);
-    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = (__bf16)src[i];
+        reinterpret_cast<bf16x4_t*>(dst)[i] = __builtin_convertvector(reinterpret_cast<const f32x4*>(src)[i] * scale, bf16x4_t);
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = (__bf16)(src[i] * scale);
 }
 
 __global__ __launch_bounds__(256) void unpack_bf16_kernel(const __bf16* __restrict__ src, float* __restrict__ dst, long n) {
@@ -70,14 +70,16 @@ __global__ __launch_bounds__(256) void unpack_bf16_kernel(const __bf16* __restri
 extern "C" {
 
 // fp32 -> bf16 (round to nearest even) / bf16 -> fp32 over n elements: the gradient-bucket wire format
-int cswin_pack_bf16(const float* src, void* dst, long n, void* stream) {
+int cswin_pack_bf16_scaled(const float* src, void* dst, long n, float scale, void* stream) {
     CSWIN_REQUIRE(src && dst && n > 0, CSWIN_ERR_SHAPE, "pack_bf16: bad arguments");
     CSWIN_REQUIRE((((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 7) == 0, CSWIN_ERR_ALIGN, "pack_bf16: src 16-B / dst 8-B alignment required");
     long b = (n / 4 + 255) / 256;
-    hipLaunchKernelGGL(pack_bf16_kernel, dim3((int)(b < 1 ? 1 : (b > 4096 ? 4096 : b))), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, n);
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((int)(b < 1 ? 1 : (b > 4096 ? 4096 : b))), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, n, scale);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }
+
+int cswin_pack_bf16(const float* src, void* dst, long n, void* stream) { return cswin_pack_bf16_scaled(src, dst, n, 1.0f, stream); }
 
 int cswin_unpack_bf16(const void* src, float* dst, long n, void* stream) {
     CSWIN_REQUIRE(src && dst && n > 0, CSWIN_ERR_SHAPE, "unpack_bf16: bad arguments");

@@ -12,9 +12,7 @@ struct CswinTuning {
     double gemm_pen2;
     // bf16 mode
     int wgrad16_on, w16_wgs, w16_even, w16_dma;             // wgrad16.hip
-    int gemm16_on, gemm16_stages, gemm16_kg, gemm16_tm;     // gemm16.hip
-    // weight-stationary family (wsgemm.hip)
-    int ws_gemm, ws_nwn, ws_nwk;
+    int gemm16_on, gemm16_stages, gemm16_tm;                // gemm16.hip
     // attention, CARAFE
     int attn_bwd_two_pass, attn_fwd_qsplit, carafe_generic;
 };
@@ -36,13 +34,7 @@ inline const CswinTuning& cswin_tuning() {
         c.w16_dma = geti("CSWIN_W16_DMA", 1);                    // 0 = register path for every problem
         c.gemm16_on = geti("CSWIN_GEMM16", 1);                   // 0 = tiled family where the LDS-DMA GEMM would run
         c.gemm16_stages = geti("CSWIN_GEMM16_STAGES", 0);        // 2 .. 4 steps in flight, 0 = default (3)
-        c.gemm16_kg = geti("CSWIN_GEMM16_KG", 0);                // 2 = two k-groups for long reductions
         c.gemm16_tm = geti("CSWIN_GEMM16_TM", 0);                // 64 / 128 tile rows, 0 = by workgroup count
-        c.ws_gemm = geti("CSWIN_WS_GEMM", 0);                    // 0 never, 1 wherever a layout exists, 2 by cost model
-        if (const char* f = getenv("CSWIN_WS_LAYOUT")) {         // "nwn,nwk" forces a wave layout where it fits
-            int a = 0, b = 0;
-            if (sscanf(f, "%d,%d", &a, &b) == 2) { c.ws_nwn = a; c.ws_nwk = b; }
-        }
         c.attn_bwd_two_pass = getenv("CSWIN_ATTN_BWD_TWO_PASS") != nullptr;      // large-window backward for every window size
         c.attn_fwd_qsplit = geti("CSWIN_ATTN_FWD_QSPLIT", 0);    // 1 / 2 query-split workgroups per unit, 0 = heuristic
         c.carafe_generic = getenv("CSWIN_CARAFE_GENERIC") != nullptr;            // disable the fused CARAFE4 backward

@@ -16,60 +16,9 @@ __all__ = ["layer_norm", "linear", "linear_pair", "mlp", "stripe_attention", "cs
            "tokens_to_nchw", "matmul_nn", "ce_dice_loss", "dropout", "img2windows", "windows2img"]
 
 
-# ------------------------------------------------------------------------------------------------
-# weight-gradient side stream
-# ------------------------------------------------------------------------------------------------
-# In backward, a layer's weight gradient (split-K GEMM + slab reduction) is independent of the data-gradient chain that
-# the next layer waits for.  When enabled (HipEngine does; default off so that `loss.backward(); torch.optim.step()`
-# stays a plain single-stream program), weight-gradient launches go to a second HIP stream forked from the current
-# one, so the two chains fill each other's launch ramps and tails (every kernel of this model is 10-50 us).  The fork /
-# join edges are ordinary events, so the same code is captured into hipGraphs as parallel branches.
-_overlap = {"on": False, "stream": None, "pending": [], "block": False}
-
-
-def set_block_overlap(enabled: bool):
-    """CSWinBlock backward: launch the three weight gradients that are ready before the attention backward (fc2, fc1, proj)
-    on the side stream, so that they run beside the attention kernel (384 seven-wave workgroups at B = 24: half of the
-    CUs hold one, with LDS and wave slots to spare) instead of after it."""
-    _overlap["block"] = bool(enabled)
-
-
-def set_wgrad_overlap(enabled: bool):
-    _overlap["on"] = bool(enabled)
-
-
-class _side_stream:
-    """with _side_stream(*tensors): launches inside go to the side stream, ordered after everything already enqueued
-    on the current stream; `tensors` (inputs living on the main stream's allocator) are kept alive until
-    join_wgrad_stream() so the caching allocator cannot recycle them under the side stream."""
-
-    def __init__(self, *keep):
-        self.keep = keep
-
-    def __enter__(self):
-        if not _overlap["on"]:
-            self.ctx = None
-            return self
-        if _overlap["stream"] is None:
-            _overlap["stream"] = torch.cuda.Stream()
-        side = _overlap["stream"]
-        side.wait_stream(torch.cuda.current_stream())
-        _overlap["pending"].append(self.keep)
-        self.ctx = torch.cuda.stream(side)
-        self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-        return False
-
-
 def join_wgrad_stream():
-    """Make the current stream wait for every weight gradient launched on the side stream (call before reading .grad)."""
-    if _overlap["stream"] is not None and _overlap["pending"]:
-        torch.cuda.current_stream().wait_stream(_overlap["stream"])
-    _overlap["pending"].clear()
+    """Kept for callers of round-2 code: weight gradients run on the calling stream (the side-stream variants measured slower
+    under hipGraphs and were removed in round 3), so there is nothing to join."""
 
 
 def _ws(nbytes, device):
@@ -195,7 +144,7 @@ class _Linear(Function):
             call("cswin_linear_bwd_data", ptr(dy), pw, ptr(dx), ptr(dx2), K1 if x2 is not None else 0, None,
                  ptr(row_scale), ctx.rps, None, M, N, K, precision(), fw, stream())
         if need[1]:
-            with _side_stream(dy, x, x2, row_scale):
+            if True:
                 dw = torch.empty_like(w)
                 db = torch.empty(N, dtype=torch.float32, device=w.device) if ctx.has_bias else None
                 nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
@@ -324,7 +273,7 @@ class _Mlp(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             call("cswin_linear_bwd_data", ptr(dpre), ptr(w1), ptr(dx), None, 0, None, None, 1, None, M, Hd, K, precision(), 0, st)
-        with _side_stream(dyl, act, dpre, x, rs_gemm):          # both weight gradients, off the data-gradient chain
+        if True:                                                # both weight gradients
             dw2 = torch.empty_like(w2)
             db2 = torch.empty(N, dtype=torch.float32, device=dev) if ctx.has_b2 else None
             nbytes = max(lib().cswin_linear_bwd_weight_workspace(M, N, Hd), lib().cswin_linear_bwd_weight_workspace(M, Hd, K))
@@ -548,16 +497,6 @@ class _CSWinBlock(Function):
              fp | (1 if s16 else 0), st)
         dwp, dbp = torch.empty_like(wp), E(C)
         defer_wgrad(2, dx1_16 if s16 else dx1, att, rs1, dwp, dbp, 3, C, C, io=3)      # dx1's twin and x = att are stored as bf16
-        early = None
-        if _overlap["block"]:
-            # fc2, fc1 and proj weight gradients have all their operands now: they run BESIDE the attention backward
-            early = (ReduceJob * 3)()
-            if _overlap["stream"] is None:
-                _overlap["stream"] = torch.cuda.Stream()
-            side = _overlap["stream"]
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 3, ctypes.cast(early, ctypes.c_void_p), stream())
         dqkv = torch.empty_like(qkv)
         dlw = [torch.empty_like(t) for t in lw]
         dlb = [E(t.shape[0]) for t in lw]
@@ -570,13 +509,7 @@ class _CSWinBlock(Function):
         dbqkv = E(3 * C) if has_qkv_bias else None
         defer_wgrad(3, dqkv, h1, None, dwqkv, dbqkv, 4, 3 * C, C, io=3)  # dy = dqkv and x = h1 are stored as bf16
         wjobs = (ReduceJob * 4)()
-        if early is not None:
-            call("cswin_linear_bwd_weight_batch", ctypes.cast(ctypes.byref(wg[3]), ctypes.c_void_p), 1,
-                 ctypes.cast(ctypes.byref(wjobs[3]), ctypes.c_void_p), st)
-            for slot in range(3):
-                wjobs[slot] = early[slot]
-        else:
-            call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(wjobs, ctypes.c_void_p), st)
+        call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(wjobs, ctypes.c_void_p), st)
         for slot, ji in enumerate((0, 1, 3, 4)):
             jobs[ji] = wjobs[slot]
         dh1 = datt                                                     # reuse again
@@ -587,8 +520,6 @@ class _CSWinBlock(Function):
              sizes[5], M, C, J(5), ptr(dx16), st)
         if s16:
             _twin_put(dx, dx16)
-        if early is not None:
-            torch.cuda.current_stream().wait_stream(_overlap["stream"])      # slabs of the early weight gradients are complete
         call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), 6 + nb, st)
         grads = (dx, None, None, None, None, None, None, None, None, None, None, dg1, dbt1, dwqkv, dbqkv, dwp, dbp, dg2, dbt2, dw1, db1,
                  dw2, db2)
@@ -654,7 +585,7 @@ class _ConvTokens(Function):
                 if wpt is None:
                     _, wpt = _permute_w(w, Cin, True)
                 call("cswin_conv_tok_bwd_data", ptr(dy), ptr(wpt), ptr(dx), B, H, W, Cin, Cout, ks, stride, pad, precision(), st)
-        with _side_stream(dy, x):
+        if True:
             dw = torch.empty_like(w)                    # written in the parameter layout by the slab reduction itself
             db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_b else None
             nbytes = lib().cswin_conv_tok_bwd_weight_workspace(B, H, W, Cin, Cout, ks, stride, pad)

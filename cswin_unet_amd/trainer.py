@@ -98,9 +98,6 @@ class HipEngine:
             use_graph = False
         self.use_graph, self._graphs, self._logits = use_graph, None, None
         self._wire = {}
-        from . import ops
-        ops.set_wgrad_overlap(os.environ.get("CSWIN_WGRAD_OVERLAP", "0") != "0")
-        ops.set_block_overlap(os.environ.get("CSWIN_BLOCK_OVERLAP", "0") != "0")
 
     # flat views the protocol all-reduces / broadcasts
     @property
@@ -270,14 +267,14 @@ class HipEngine:
         self.opt.apply(grad_scale)
 
     # bf16 gradient wire (HIP kernels; the wire buffer of a bucket is allocated once and reused every step)
-    def pack_wire(self, chunk, dtype):
+    def pack_wire(self, chunk, dtype, scale=1.0):
         if dtype != torch.bfloat16:
             raise ValueError(f"HipEngine wire dtype {dtype}: only torch.bfloat16 is implemented")
         key = (chunk.data_ptr(), chunk.numel())
         wire = self._wire.get(key)
         if wire is None:
             wire = self._wire[key] = torch.empty(chunk.numel(), dtype=torch.bfloat16, device=chunk.device)
-        call("cswin_pack_bf16", ptr(chunk), ptr(wire), chunk.numel(), stream())
+        call("cswin_pack_bf16_scaled", ptr(chunk), ptr(wire), chunk.numel(), float(scale), stream())
         return wire
 
     def unpack_wire(self, wire, chunk):
@@ -311,6 +308,34 @@ class DataParallelTrainer:
     def stats(self):
         return self.engine.stats
 
+    # ---- per-phase timing of the backward / all-reduce / update part of a step (bench.py's dp_diagnostics) ----
+    _timing = None
+
+    def _mark(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def enable_timing(self, on=True):
+        """Record a HIP event on the compute stream after the loss, after every backward phase, before and after the loop that
+        makes the compute stream wait for the collectives (+ the bf16 unpack kernels) and after the update, for the steps that
+        follow.  The wait-loop interval is the all-reduce time the backward did NOT hide."""
+        self._timing = {"ev": [], "bucket_bytes": []} if on else None
+
+    def collect_timing(self):
+        """Mean milliseconds per recorded step: backward phases (in order), exposed all-reduce (+ unpack), update."""
+        tm = self._timing
+        if not tm or not tm["ev"]:
+            return None
+        torch.cuda.synchronize()
+        rows = [[a.elapsed_time(b) for a, b in zip(ev[:-1], ev[1:])] for ev in tm["ev"]]
+        mean = [sum(r[i] for r in rows) / len(rows) for i in range(len(rows[0]))]
+        nph = len(mean) - 3          # events: loss | after each phase (its buckets enqueued) | before the waits | after them | after the update
+        return {"steps": len(rows), "backward_phase_ms": [round(v, 3) for v in mean[:nph]],
+                "allreduce_exposed_ms": round(mean[nph] + mean[nph + 1], 3), "update_ms": round(mean[nph + 2], 3),
+                "bucket_bytes": tm["bucket_bytes"], "wire": "bf16 (pre-divided by world)" if self.allreduce_dtype is not None else "fp32",
+                "world": self.world}
+
     def train_step(self, img, lab):
         """One optimisation step on this rank's shard.  Returns the device tensor [loss, ce, dice] (no host sync)."""
         if lab.dtype != torch.int64:
@@ -323,8 +348,14 @@ class DataParallelTrainer:
         if self.collectives:
             dist.all_reduce(eng.sums, group=self.group)                 # 1 + 3*ncls floats
         eng.finalize(lab.numel() * world)
+        tm = self._timing
+        if tm is not None:
+            tm["ev"].append([self._mark()])
         works = []
+        wired = self.collectives and self.allreduce_dtype is not None
         for lo, hi in eng.backward_phases(dice_grad_scale=float(world)):
+            if tm is not None:
+                tm["ev"][-1].append(self._mark())
             if self.collectives:
                 # this phase's gradients are final: put them on the wire now (RCCL runs on its own stream, ordered after
                 # the work enqueued so far) while the next backward phase computes.  Few large buckets: xGMI is 7
@@ -334,12 +365,18 @@ class DataParallelTrainer:
                 step = (step + 63) // 64 * 64                                             # buckets start 256-B aligned
                 for o in range(lo, hi, step):
                     chunk = g[o:min(o + step, hi)]
-                    if self.allreduce_dtype is None:
+                    if tm is not None and len(tm["ev"]) == 1:
+                        tm["bucket_bytes"].append(chunk.numel() * (2 if wired else 4))
+                    if not wired:
                         works.append((dist.all_reduce(chunk, group=self.group, async_op=True), None, None))
                     else:
+                        # bf16 wire: the bucket is packed PRE-DIVIDED by the world size, so the collective's bf16 sum is the mean
+                        # itself (no mantissa bits spent on a factor that is divided out again) and apply() below scales by 1
                         pack = getattr(eng, "pack_wire", None)          # HipEngine: HIP pack kernel into a persistent wire buffer
-                        wire = pack(chunk, self.allreduce_dtype) if pack else chunk.to(self.allreduce_dtype)
+                        wire = pack(chunk, self.allreduce_dtype, 1.0 / world) if pack else (chunk / world).to(self.allreduce_dtype)
                         works.append((dist.all_reduce(wire, group=self.group, async_op=True), chunk, wire))
+        if tm is not None:
+            tm["ev"][-1].append(self._mark())
         for w, chunk, wire in works:
             w.wait()
             if wire is not None:
@@ -348,7 +385,11 @@ class DataParallelTrainer:
                     unpack(wire, chunk)
                 else:
                     chunk.copy_(wire)
-        eng.apply(grad_scale=1.0 / world)
+        if tm is not None:
+            tm["ev"][-1].append(self._mark())
+        eng.apply(grad_scale=1.0 if wired else 1.0 / world)
+        if tm is not None:
+            tm["ev"][-1].append(self._mark())
         self.iter_num += 1
         eng.set_lr(poly_lr(self.base_lr, self.iter_num - 1, self.max_iterations))   # trainer.py:61-63
         return eng.stats

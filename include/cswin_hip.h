@@ -229,6 +229,9 @@ int cswin_dropout(const float* x, const float* residual, const float* row_scale,
 /* bf16 gradient wire for the data-parallel all-reduce (replaces DataParallel's fp32 reduce_add, trainer.py:37-38):
    fp32 -> bf16 round-to-nearest-even / bf16 -> fp32 over n elements (src of pack, dst of unpack 16-B aligned) */
 int cswin_pack_bf16(const float* src, void* dst_bf16, long n, void* stream);
+/* dst = bf16(scale * src): the trainer packs gradient buckets pre-divided by the world size, so the collective's bf16 sum IS the
+   mean (eight ranks' sum would otherwise spend three of bf16's eight mantissa bits on the factor 8 it is divided by afterwards) */
+int cswin_pack_bf16_scaled(const float* src, void* dst_bf16, long n, float scale, void* stream);
 int cswin_unpack_bf16(const void* src_bf16, float* dst, long n, void* stream);
 
 #ifdef __cplusplus

@@ -80,17 +80,18 @@ class OracleEngine:
         self.flat_param.sub_(self.lr * self.flat_mom)
 
 
-def _run(rank, world, port, out, wire_dtype=None):
+def _run(rank, world, port, out, wire_dtype=None, batch=2):
     from cswin_unet_amd.trainer import DataParallelTrainer
     group = None
     if world > 1:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
         group = dist.group.WORLD
     torch.set_num_threads(2)
-    img = torch.from_numpy(det_normal("dp.img", (2, 3, 64, 64)))
-    lab = torch.from_numpy(det_labels("dp.lab", (2, 64, 64), CFG["num_classes"]))
+    img = torch.from_numpy(det_normal("dp.img", (batch, 3, 64, 64)))
+    lab = torch.from_numpy(det_labels("dp.lab", (batch, 64, 64), CFG["num_classes"]))
     if world > 1:
-        img, lab = img[rank:rank + 1], lab[rank:rank + 1]
+        per = batch // world
+        img, lab = img[rank * per:(rank + 1) * per], lab[rank * per:(rank + 1) * per]
     tr = DataParallelTrainer(engine=OracleEngine(lr=0.05), base_lr=0.05, max_iterations=10, group=group, buckets=3,
                              allreduce_dtype=wire_dtype)
     hist = []
@@ -158,3 +159,43 @@ def test_two_ranks_bf16_gradient_wire():
     assert 0 < dw < 2 ** -7 * step * 40, dw                                               # bf16 rounding of the update, not garbage
     assert np.allclose(single["stats"][1], multi["stats"][1], rtol=5e-3)
 
+
+
+def _spawn(world, wire_dtype, batch):
+    ctx = mp.get_context("spawn")
+    q1, q2 = ctx.Queue(), ctx.Queue()
+    _run(0, 1, 0, q1, None, batch)
+    single = q1.get(timeout=120)
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, world, port, q2, wire_dtype, batch), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        multi = q2.get(timeout=480)
+    finally:
+        for p in procs:
+            p.join(120)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return single, multi
+
+
+def test_eight_ranks_equal_global_batch():
+    """The driver's SCALE run is world 8: the same protocol (28-float global-Dice all-reduce, bucket ranges of three phases, 1 / world
+    averaging, poly-LR) on 8 gloo ranks with one image each == one process on the batch of 8."""
+    single, multi = _spawn(8, None, 8)
+    assert np.allclose(single["stats"], multi["stats"], rtol=5e-5, atol=1e-6), (single["stats"], multi["stats"])
+    assert np.allclose(single["w"], multi["w"], rtol=2e-4, atol=4e-6)
+    assert single["lr"] == multi["lr"]
+
+
+def test_eight_ranks_bf16_wire_carries_the_mean():
+    """bf16 wire at world 8: buckets are packed pre-divided by the world size, so the collective's bf16 sum is the gradient MEAN
+    (not an 8-fold sum that is divided afterwards).  Every addend and every partial sum is then at the scale of the result: the
+    update stays within bf16 rounding of the fp32-wire run, as at world 2."""
+    single, multi = _spawn(8, torch.bfloat16, 8)
+    assert np.allclose(single["stats"][0], multi["stats"][0], rtol=5e-5, atol=1e-6)      # first loss: no gradient used yet
+    dw = np.abs(single["w"] - multi["w"]).max()
+    assert 0 < dw < 2 ** -7 * 0.05 * 40, dw
+    assert np.allclose(single["stats"][1], multi["stats"][1], rtol=5e-3)

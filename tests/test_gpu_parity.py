@@ -1196,6 +1196,108 @@ def test_full_size_training_step_384_b8_vs_oracle(N, ops):
     _full_size_step(N, ops, 384, 8, (1, 2, 12, 12), "full384b8")
 
 
+def _full_size_step_bf16(N, ops, net, cfg, img, lab, tag, grads, logits_bound, grad_bound):
+    """One whole bf16-mode training step at a BASELINE size against the fp32 CPU oracle, L2 bounds as derived for the small bf16
+    model tests (sigma = 1.6e-3 per GEMM, errors add in quadrature along the chain; logged to parity_errors.log)."""
+    logits = net(img.to(DEV))
+    loss, stats = ops.ce_dice_loss(logits, lab.to(DEV))
+    loss.backward()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    P = O.golden_params(cfg)
+    ref_logits = O.cswin_forward(P, img, cfg)
+    ref_loss, _, _ = O.ce_dice_loss(ref_logits, lab)
+    ref_loss.backward()
+    e = _rel_l2(logits, ref_logits)
+    with open(LOG, "a") as f:
+        f.write(f"{tag}.logits l2 {e:.3e}\n")
+    assert 1e-4 < e < logits_bound, e
+    assert abs(float(loss) - float(ref_loss)) < 1e-2 * abs(float(ref_loss))
+    params = dict(net.named_parameters())
+    for n in grads:
+        e = _rel_l2(params[n].grad, P[n].grad)
+        with open(LOG, "a") as f:
+            f.write(f"{tag}.grad.{n} l2 {e:.3e}\n")
+        assert e < grad_bound, (n, e)
+
+
+def test_full_size_training_step_b24_bf16_vs_oracle(N, ops, bf16_matmul):
+    """BASELINE configs[2]'s per-GPU workload exactly as bench.py's bf16_mode key times it (cswin_tiny_224_lite, B = 24, bf16
+    operands / activations / attention products): logits and the 33 gradients of FULL_GRADS against the fp32 oracle."""
+    net = N.CSWinTransformer(img_size=224, num_classes=9, embed_dim=64, depth=[1, 2, 9, 1], split_size=[1, 2, 7, 7],
+                             num_heads=[2, 4, 8, 16], qkv_bias=True, drop_path_rate=0.).to(DEV)
+    fill_state_dict(net).train()
+    g = torch.Generator().manual_seed(20260)
+    img = torch.randn(24, 3, 224, 224, generator=g)
+    lab = torch.randint(0, 9, (24, 224, 224), generator=g)
+    _full_size_step_bf16(N, ops, net, dict(O.TINY_224), img, lab, "full224b24.bf16", FULL_GRADS, BF16_LOGITS_L2, BF16_GRAD_L2)
+
+
+def test_full_size_training_step_384_b8_bf16_vs_oracle(N, ops, bf16_matmul):
+    """BASELINE configs[3] (384 x 384, split [1,2,12,12], B = 8 per GPU) in its own precision."""
+    cfg = dict(O.TINY_224, img_size=384, split_size=(1, 2, 12, 12))
+    net = N.CSWinTransformer(img_size=384, num_classes=9, embed_dim=64, depth=[1, 2, 9, 1], split_size=[1, 2, 12, 12],
+                             num_heads=[2, 4, 8, 16], qkv_bias=True, drop_path_rate=0.).to(DEV)
+    fill_state_dict(net).train()
+    g = torch.Generator().manual_seed(20261)
+    img = torch.randn(8, 3, 384, 384, generator=g)
+    lab = torch.randint(0, 9, (8, 384, 384), generator=g)
+    _full_size_step_bf16(N, ops, net, cfg, img, lab, "full384b8.bf16", FULL_GRADS, BF16_LOGITS_L2, BF16_GRAD_L2)
+
+
+# cswin_base_224 at its OWN size (BASELINE configs[4]: embed_dim 96, depth [2, 4, 32, 2], heads [4, 8, 16, 32], B = 8 per GPU): 148 chained
+# GEMMs per direction, head dim 24, the B-dependent GEMM / attention dispatch of that shape.  Oracle only (the reference cannot
+# construct embed_dim != 64).
+BASE_CFG = dict(O.TINY_224, embed_dim=96, depth=(2, 4, 32, 2), num_heads=(4, 8, 16, 32))
+BASE_GRADS = ["stage1_conv_embed.0.weight", "stage1.1.qkv.weight", "stage1.0.attns.0.get_v.weight", "merge1.conv.weight",
+              "stage2.3.mlp.fc1.weight", "stage2.0.attns.1.get_v.bias", "merge2.conv.weight", "stage3.0.proj.weight",
+              "stage3.15.qkv.weight", "stage3.31.mlp.fc2.weight", "stage3.20.attns.1.get_v.weight", "stage3.7.norm1.weight",
+              "merge3.conv.weight", "stage4.1.qkv.bias", "stage4.0.attns.0.get_v.weight", "norm.weight",
+              "stage_up4.1.mlp.fc1.weight", "upsample4.encoder.weight", "concat_linear4.weight", "stage_up3.0.qkv.weight",
+              "stage_up3.31.norm2.bias", "stage_up3.16.proj.weight", "upsample3.down.weight", "concat_linear3.weight",
+              "stage_up2.2.proj.weight", "upsample2.encoder.weight", "concat_linear2.weight", "stage_up1.1.mlp.fc2.weight",
+              "upsample1.encoder.weight", "upsample1.out.weight", "norm_up.weight", "output.weight"]
+
+
+def _base_model(N):
+    net = N.CSWinTransformer(img_size=224, num_classes=9, embed_dim=96, depth=[2, 4, 32, 2], split_size=[1, 2, 7, 7],
+                             num_heads=[4, 8, 16, 32], qkv_bias=True, drop_path_rate=0.).to(DEV)
+    return fill_state_dict(net).train()
+
+
+def test_cswin_base_full_depth_step_b8_vs_oracle(N, ops):
+    """fp32: logits, loss, CE, Dice and 32 gradients spread over all 76 blocks at RTOL 1e-3."""
+    net = _base_model(N)
+    g = torch.Generator().manual_seed(20262)
+    img = torch.randn(8, 3, 224, 224, generator=g)
+    lab = torch.randint(0, 9, (8, 224, 224), generator=g)
+    logits = net(img.to(DEV))
+    loss, stats = ops.ce_dice_loss(logits, lab.to(DEV))
+    loss.backward()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    P = O.golden_params(BASE_CFG)
+    ref_logits = O.cswin_forward(P, img, BASE_CFG)
+    ref_loss, ref_ce, ref_dice = O.ce_dice_loss(ref_logits, lab)
+    ref_loss.backward()
+    rel_err(logits, ref_logits, "baseb8.logits")
+    assert abs(float(loss) - float(ref_loss)) < 1e-3 * abs(float(ref_loss))
+    assert abs(float(stats[1]) - float(ref_ce)) < 1e-3 * abs(float(ref_ce)) and abs(float(stats[2]) - float(ref_dice)) < 1e-3 * abs(float(ref_dice))
+    params = dict(net.named_parameters())
+    assert set(params) == set(P)
+    for n in BASE_GRADS:
+        rel_err(params[n].grad, P[n].grad, f"baseb8.grad.{n}")
+
+
+def test_cswin_base_full_depth_step_b8_bf16_vs_oracle(N, ops, bf16_matmul):
+    """bf16 mode.  The small-model bounds (3e-2 logits, 5e-2 gradients) were derived for ~60 chained GEMMs; 148 of them scale the
+    quadrature sum by sqrt(148 / 60) = 1.57: 5e-2 and 8e-2."""
+    net = _base_model(N)
+    g = torch.Generator().manual_seed(20262)
+    img = torch.randn(8, 3, 224, 224, generator=g)
+    lab = torch.randint(0, 9, (8, 224, 224), generator=g)
+    _full_size_step_bf16(N, ops, net, BASE_CFG, img, lab, "baseb8.bf16", BASE_GRADS, 5e-2, 8e-2)
+
+
+
 def test_use_chk_with_drop_path_matches_plain_backward(N, ops):
     """Activation checkpointing (use_chk, cswin_unet.py:329-331,468-532) with stochastic depth: the recompute in backward
     must reuse the DropPath factors the forward drew (they used to be popped and re-drawn)."""
