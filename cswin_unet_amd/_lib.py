@@ -39,7 +39,7 @@ SIGNATURES = {
     "cswin_conv_tok_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "cswin_conv_tok_bwd_data": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "cswin_conv_tok_bwd_weight_workspace": (SZ, [I, I, I, I, I, I, I, I]),
-    "cswin_conv_tok_bwd_weight": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, I, I, I, I, P]),
+    "cswin_conv_tok_bwd_weight": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, I, I, I, P, I, P]),
     "cswin_conv_weight_permute": (I, [P, P, P, I, I, I, I, P]),
     "cswin_conv_weight_unpermute": (I, [P, P, I, I, I, I, P]),
     "cswin_conv_weight_flipT": (I, [P, P, I, I, I, P]),
@@ -72,7 +72,8 @@ class WgradDesc(ctypes.Structure):
 class ReduceJob(ctypes.Structure):
     """Mirror of cswin_reduce_job (include/cswin_hip.h)."""
     _fields_ = [("part", c_void_p), ("out", c_void_p), ("out2", c_void_p), ("n_first", ctypes.c_longlong),
-                ("n", ctypes.c_longlong), ("stride", ctypes.c_longlong), ("rows", c_int), ("reserved", c_int)]
+                ("n", ctypes.c_longlong), ("stride", ctypes.c_longlong), ("rows", c_int), ("reserved", c_int),
+                ("conv_kk", c_int), ("conv_cin", c_int)]
 
 
 _lib = None

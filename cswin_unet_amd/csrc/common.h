@@ -95,6 +95,8 @@ typedef struct cswin_reduce_job {
     float* out2;             // columns [n_first, n) (may be NULL: then everything goes to out)
     long long n_first, n, stride;
     int rows, reserved;      // reserved: set by the library (bit 0 = 16-B loads are legal)
+    int conv_kk, conv_cin;   // != 0: columns [0, n_first) are a conv weight gradient in the implicit-GEMM order [Cout][k*k][Cin],
+                             // stored to `out` in the nn.Conv2d order [Cout][Cin][k][k] (conv_kk = k*k, conv_cin = Cin)
 } cswin_reduce_job;
 }
 
@@ -144,13 +146,12 @@ __device__ __forceinline__ void rows_sum_block(const cswin_reduce_job& job, long
 // Same reduction for a convolution weight gradient whose slab columns are [Cout][k*k][Cin] (the implicit-GEMM order) while
 // the parameter is [Cout][Cin][k][k]: slabs are read along their columns (coalesced), the nn.Conv2d layout is produced by the
 // 4-B stores of the (small) result.  Columns >= n_first are the bias gradient as usual.
-static __global__ __launch_bounds__(256) void rows_sum_conv_kernel(cswin_reduce_job job, int kk, int Cin) {
-    __shared__ float red[RS_G][RS_COLS + 1];
-    cswin_reduce_job j = job;
+__device__ __forceinline__ void rows_sum_conv_block(const cswin_reduce_job& j, long blk, float (*red)[RS_COLS + 1]) {
+    const int kk = j.conv_kk, Cin = j.conv_cin;
     float* out = j.out;
     // reduce into LDS exactly like rows_sum_block, then remap the store
     const int c4 = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const long i0 = (long)blockIdx.x * RS_COLS + 4 * c4;
+    const long i0 = blk * RS_COLS + 4 * c4;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
     if (i0 < j.n) {
         const float* base = j.part + i0;
@@ -172,7 +173,7 @@ static __global__ __launch_bounds__(256) void rows_sum_conv_kernel(cswin_reduce_
 #pragma unroll
     for (int e = 0; e < 4; ++e) red[g][4 * c4 + e] = s0[e];
     __syncthreads();
-    const long i = (long)blockIdx.x * RS_COLS + threadIdx.x;
+    const long i = blk * RS_COLS + threadIdx.x;
     if (threadIdx.x < RS_COLS && i < j.n) {
         float t = 0.f;
 #pragma unroll
@@ -201,7 +202,7 @@ typedef struct cswin_wgrad_desc {
 } cswin_wgrad_desc;
 }
 
-constexpr int CSWIN_MAX_REDUCE_JOBS = 8;
+constexpr int CSWIN_MAX_REDUCE_JOBS = 48;          // one launch's kernel arguments: 48 x 64 B + 49 x 4 B < 4 KB
 struct ReduceJobs {
     cswin_reduce_job j[CSWIN_MAX_REDUCE_JOBS];
     int first_block[CSWIN_MAX_REDUCE_JOBS + 1];
@@ -229,19 +230,20 @@ __device__ __forceinline__ void rows_sum_few(const cswin_reduce_job& job, long b
 }
 // reserved bit 1 (set by cswin_rows_sum_multi): this job runs in the few-rows mode (needs bit 0 and 16-B aligned outputs)
 static inline int reduce_job_few_ok(const cswin_reduce_job& j) {
-    return reduce_job_vec_ok(j) && j.rows <= RS_FEW_ROWS && j.n >= 4 * RS_FEW_COLS && ((uintptr_t)j.out % 16 == 0) &&
+    return !j.conv_kk && reduce_job_vec_ok(j) && j.rows <= RS_FEW_ROWS && j.n >= 4 * RS_FEW_COLS && ((uintptr_t)j.out % 16 == 0) &&
            (!j.out2 || ((uintptr_t)j.out2 % 16 == 0));
 }
 
 static __global__ __launch_bounds__(256) void rows_sum_kernel(cswin_reduce_job job) {
     __shared__ float red[RS_G][RS_COLS + 1];
-    if (job.reserved & 2) rows_sum_few(job, blockIdx.x);
+    if (job.conv_kk) rows_sum_conv_block(job, blockIdx.x, red);
+    else if (job.reserved & 2) rows_sum_few(job, blockIdx.x);
     else rows_sum_block(job, blockIdx.x, red);
 }
 
 static inline void launch_rows_sum(const float* part, float* out, float* out2, long n_first, long n, int rows, long stride,
                                    hipStream_t st) {
-    cswin_reduce_job job = {part, out, out2, n_first, n, stride, rows, 0};
+    cswin_reduce_job job = {part, out, out2, n_first, n, stride, rows, 0, 0, 0};
     const int few = reduce_job_few_ok(job);
     job.reserved = reduce_job_vec_ok(job) | (few ? 2 : 0);
     const long cols = few ? RS_FEW_COLS : RS_COLS;
@@ -250,9 +252,15 @@ static inline void launch_rows_sum(const float* part, float* out, float* out2, l
 
 static __global__ __launch_bounds__(256) void rows_sum_multi_kernel(ReduceJobs J) {
     __shared__ float red[RS_G][RS_COLS + 1];
-    int k = 0;
-    while (k + 1 < J.njobs && (int)blockIdx.x >= J.first_block[k + 1]) ++k;
-    if (J.j[k].reserved & 2) rows_sum_few(J.j[k], blockIdx.x - J.first_block[k]);
+    int lo = 0, hi = J.njobs - 1;                    // the job of this workgroup: last k with first_block[k] <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)blockIdx.x >= J.first_block[mid]) lo = mid;
+        else hi = mid - 1;
+    }
+    const int k = lo;
+    if (J.j[k].conv_kk) rows_sum_conv_block(J.j[k], blockIdx.x - J.first_block[k], red);
+    else if (J.j[k].reserved & 2) rows_sum_few(J.j[k], blockIdx.x - J.first_block[k]);
     else rows_sum_block(J.j[k], blockIdx.x - J.first_block[k], red);
 }
 

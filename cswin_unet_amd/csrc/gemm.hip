@@ -1041,7 +1041,7 @@ size_t cswin_conv_tok_bwd_weight_workspace(int B, int H, int W, int Cin, int Cou
 // dw_perm: [Cout][ks*ks][Cin], or the nn.Conv2d parameter layout [Cout][Cin][ks][ks] when torch_layout != 0; dbias: [Cout]
 int cswin_conv_tok_bwd_weight(const float* dy, const float* x, float* dw_perm, float* dbias, void* workspace,
                               size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ks, int stride, int pad,
-                              int torch_layout, int precision, void* stream) {
+                              int torch_layout, cswin_reduce_job* deferred, int precision, void* stream) {
     CSWIN_CHECK_PRECISION(precision, "conv_tok_bwd_weight");
     CSWIN_REQUIRE(dy && x && dw_perm, CSWIN_ERR_SHAPE, "conv_tok_bwd_weight: null pointer");
     CSWIN_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0 && aligned16(dy) && aligned16(x), CSWIN_ERR_ALIGN, "conv_tok_bwd_weight: channels %% 4 and 16-B alignment required");
@@ -1063,10 +1063,14 @@ int cswin_conv_tok_bwd_weight(const float* dy, const float* x, float* dw_perm, f
     launch_gemm<false, false, 4, EPI_PLAIN, false>(A, Bm, e, Cout, K, M, splits, rps, precision, st);
     CSWIN_LAUNCH_CHECK();
     long n = (long)Cout * K;
+    cswin_reduce_job job = {slab, dw_perm, dbias, n, n + (dbias ? Cout : 0), slab_stride, splits, 0, torch_layout ? ks * ks : 0, torch_layout ? Cin : 0};
+    if (deferred) {
+        *deferred = job;
+        return CSWIN_OK;
+    }
     if (torch_layout) {
-        cswin_reduce_job job = {slab, dw_perm, dbias, n, n + (dbias ? Cout : 0), slab_stride, splits, 0};
         job.reserved = reduce_job_vec_ok(job);
-        hipLaunchKernelGGL(rows_sum_conv_kernel, dim3((unsigned)((job.n + RS_COLS - 1) / RS_COLS)), dim3(256), 0, st, job, ks * ks, Cin);
+        hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((job.n + RS_COLS - 1) / RS_COLS)), dim3(256), 0, st, job);
     } else {
         launch_rows_sum(slab, dw_perm, dbias, n, n + (dbias ? Cout : 0), splits, slab_stride, st);
     }
@@ -1074,7 +1078,7 @@ int cswin_conv_tok_bwd_weight(const float* dy, const float* x, float* dw_perm, f
     return CSWIN_OK;
 }
 
-// jobs: HOST array of njobs (<= 8) reductions left pending by *_bwd_weight / layernorm_bwd calls with `deferred` set
+// jobs: HOST array of njobs (<= CSWIN_MAX_REDUCE_JOBS = 48) reductions left pending by *_bwd_weight / layernorm_bwd calls with `deferred` set
 int cswin_rows_sum_multi(const cswin_reduce_job* jobs, int njobs, void* stream) {
     CSWIN_REQUIRE(jobs && njobs > 0 && njobs <= CSWIN_MAX_REDUCE_JOBS, CSWIN_ERR_SHAPE, "rows_sum_multi: 1..%d jobs", CSWIN_MAX_REDUCE_JOBS);
     ReduceJobs J = {};
@@ -1082,6 +1086,7 @@ int cswin_rows_sum_multi(const cswin_reduce_job* jobs, int njobs, void* stream) 
     for (int i = 0; i < njobs; ++i) {
         CSWIN_REQUIRE(jobs[i].part && jobs[i].out && jobs[i].n > 0 && jobs[i].rows > 0, CSWIN_ERR_SHAPE, "rows_sum_multi: bad job %d", i);
         J.j[i] = jobs[i];
+        CSWIN_REQUIRE((jobs[i].conv_kk == 0) == (jobs[i].conv_cin == 0) && jobs[i].conv_kk >= 0, CSWIN_ERR_SHAPE, "rows_sum_multi: job %d: conv_kk / conv_cin", i);
         const int few = reduce_job_few_ok(jobs[i]);
         J.j[i].reserved = reduce_job_vec_ok(jobs[i]) | (few ? 2 : 0);
         J.first_block[i] = blocks;

@@ -21,6 +21,103 @@ def join_wgrad_stream():
     under hipGraphs and were removed in round 3), so there is nothing to join."""
 
 
+# ------------------------------------------------------------------------------------------------
+# slab reductions and gradient placement of a backward pass
+# ------------------------------------------------------------------------------------------------
+# Every weight / LayerNorm / LePE gradient ends in a small deterministic reduction of partial slabs (cswin_reduce_job).  By
+# default an op launches its own (a CSWinBlock: its six to eight in one launch) so that the gradient tensors it returns are
+# complete when autograd sees them (accumulation into an existing .grad, hooks).  Inside `engine_backward(opt)` -- the HipEngine
+# wraps each of its backward phases in it, and owns what happens to the gradients afterwards -- two things change:
+#   * the jobs are QUEUED and reduced when the context exits, one launch per 48 jobs instead of 77 launches of ~7 us per step
+#     (30 per-block batches + 47 stand-alone ones, most of that launch floor);
+#   * parameter gradients are WRITTEN IN PLACE into the optimiser's flat gradient buffer (the reduction's output pointer is the
+#     parameter's slot), so the pass that packed them afterwards (three launches, 2 x 94 MB per step) has nothing left to copy.
+# Both rely on nobody reading a returned gradient before the context exits and on .grad being None when the pass starts.
+_rq = {"on": False, "jobs": [], "keep": [], "slots": None}
+MAX_REDUCE_JOBS = 48
+
+
+class engine_backward:
+    """with engine_backward(opt): ... one backward pass whose parameter gradients go straight to opt.flat_grad and whose slab
+    reductions run once, at exit."""
+
+    def __init__(self, opt=None):
+        self.opt = opt
+
+    def __enter__(self):
+        self.prev = (_rq["on"], _rq["slots"])
+        _rq["on"] = True
+        if self.opt is not None:
+            base = self.opt.flat_grad
+            _rq["slots"] = (base, {p.data_ptr(): (o, p.numel()) for p, o in zip(self.opt.params, self.opt.offsets)})
+        return self
+
+    def __exit__(self, *exc):
+        _rq["on"], _rq["slots"] = self.prev
+        if exc[0] is None:
+            flush_reductions()
+        else:
+            _rq["jobs"], _rq["keep"] = [], []
+        return False
+
+
+def flush_reductions():
+    jobs, _rq["jobs"] = _rq["jobs"], []
+    keep, _rq["keep"] = _rq["keep"], []
+    st = stream()
+    for i in range(0, len(jobs), MAX_REDUCE_JOBS):
+        chunk = jobs[i:i + MAX_REDUCE_JOBS]
+        arr = (ReduceJob * len(chunk))(*chunk)
+        call("cswin_rows_sum_multi", ctypes.cast(arr, ctypes.c_void_p), len(chunk), st)
+    del keep
+
+
+def _reduce_jobs(jobs, keep, leaf=True):
+    """jobs: ReduceJob structs filled by entry points called with `deferred`; keep: the workspaces they read.  leaf: every output
+    is the gradient of a leaf parameter (nothing else in this backward pass reads it), so the jobs may wait for the flush."""
+    jobs = [j for j in jobs if j.part]                    # an entry point that had nothing to reduce leaves its slot zeroed
+    if not jobs:
+        return
+    if not (leaf and _rq["on"]):                          # needed now (a composed weight's gradient feeds the next backward node)
+        arr = (ReduceJob * len(jobs))(*jobs)
+        call("cswin_rows_sum_multi", ctypes.cast(arr, ctypes.c_void_p), len(jobs), stream())
+        return
+    for j in jobs:
+        c = ReduceJob()
+        ctypes.memmove(ctypes.byref(c), ctypes.byref(j), ctypes.sizeof(ReduceJob))
+        _rq["jobs"].append(c)
+    _rq["keep"] += [t for t in keep if t is not None]
+
+
+def _all_leaf(*ts):
+    """True when every given tensor is a leaf of the autograd graph (a module parameter passed as it is, not a view or a
+    function of one): only then is its gradient final when the op returns it -- and nobody's input."""
+    return all(t is None or t.is_leaf for t in ts)
+
+
+def _grad_like(w, leaf=True):
+    """The tensor a parameter gradient is written to: the parameter's slot of the flat gradient buffer inside engine_backward (leaf
+    parameters only), a fresh tensor otherwise."""
+    return _grad_at(w.data_ptr() if leaf else 0, w.shape, w.device)
+
+
+def _grad_at(param_ptr, shape, device):
+    """Same for a parameter known by its address only (biases are not saved for backward; their data_ptr is; 0 = no slot)."""
+    slots = _rq["slots"]
+    if slots is not None and param_ptr:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        hit = slots[1].get(param_ptr)
+        if hit is not None and hit[1] == n:
+            return slots[0][hit[0]:hit[0] + n].view(shape)
+    return torch.empty(tuple(shape), dtype=torch.float32, device=device)
+
+
+def _pptr(t):
+    return t.data_ptr() if t is not None else 0
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16) // 4 + 4, dtype=torch.float32, device=device)
 
@@ -47,6 +144,8 @@ class _LayerNorm(Function):
         rstd = torch.empty_like(mean)
         call("cswin_layernorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), M, C, eps, 0, stream())
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.leaf = _all_leaf(gamma, beta)
+        ctx.beta_ptr = _pptr(beta) if ctx.leaf else 0
         return y
 
     @staticmethod
@@ -57,12 +156,14 @@ class _LayerNorm(Function):
         C = x.shape[-1]
         M = x.numel() // C
         dx = torch.empty_like(x)
-        dg = torch.empty_like(gamma)
-        db = torch.empty_like(gamma)
+        dg = _grad_like(gamma, ctx.leaf)
+        db = _grad_at(ctx.beta_ptr, gamma.shape, gamma.device)
         nbytes = lib().cswin_layernorm_bwd_workspace(M, C)
         ws = _ws(nbytes, x.device)
+        job = (ReduceJob * 1)()
         call("cswin_layernorm_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), None, ptr(dx), ptr(dg), ptr(db),
-             ptr(ws), nbytes, M, C, None, None, stream())
+             ptr(ws), nbytes, M, C, ctypes.cast(job, ctypes.c_void_p), None, stream())
+        _reduce_jobs(job, (ws,), ctx.leaf)
         return dx, dg, db, None
 
 
@@ -124,7 +225,8 @@ class _Linear(Function):
         call("cswin_linear_fwd", ptr(x), ptr(x2), K1 if x2 is not None else 0, pw, ptr(b), ptr(y), None, ptr(residual),
              ptr(row_scale), rps, M, N, K, precision(), fw, stream())
         ctx.save_for_backward(x, w, x2, row_scale)
-        ctx.has_bias, ctx.has_res, ctx.rps = b is not None, residual is not None, rps
+        ctx.leaf = _all_leaf(w, b)
+        ctx.has_bias, ctx.has_res, ctx.rps, ctx.bias_ptr = b is not None, residual is not None, rps, _pptr(b) if ctx.leaf else 0
         return y
 
     @staticmethod
@@ -145,12 +247,14 @@ class _Linear(Function):
                  ptr(row_scale), ctx.rps, None, M, N, K, precision(), fw, stream())
         if need[1]:
             if True:
-                dw = torch.empty_like(w)
-                db = torch.empty(N, dtype=torch.float32, device=w.device) if ctx.has_bias else None
+                dw = _grad_like(w, ctx.leaf)
+                db = _grad_at(ctx.bias_ptr, (N,), w.device) if ctx.has_bias else None
                 nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
                 ws = _ws(nbytes, w.device)
+                job = (ReduceJob * 1)()
                 call("cswin_linear_bwd_weight", ptr(dy), ptr(x), ptr(x2), K1 if x2 is not None else 0, ptr(row_scale), ctx.rps,
-                     ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, None, precision(), stream())
+                     ptr(dw), ptr(db), ptr(ws), nbytes, M, N, K, ctypes.cast(job, ctypes.c_void_p), precision(), stream())
+                _reduce_jobs(job, (ws,), ctx.leaf)
         dres = dy if ctx.has_res else None
         return dx, dw, db, dx2, dres, None
 
@@ -178,6 +282,8 @@ class _LinearPair(Function):
             ys.append(y)
         ctx.save_for_backward(x, w1, w2)
         ctx.has_b = (b1 is not None, b2 is not None)
+        ctx.leaf = _all_leaf(w1, b1, w2, b2)
+        ctx.bias_ptrs = (_pptr(b1), _pptr(b2)) if ctx.leaf else (0, 0)
         return tuple(ys)
 
     @staticmethod
@@ -197,8 +303,8 @@ class _LinearPair(Function):
         wg, jobs = (WgradDesc * 2)(), (ReduceJob * 2)()
         for i, (dy, w, has_b) in enumerate(((dy1, w1, ctx.has_b[0]), (dy2, w2, ctx.has_b[1]))):
             N = w.shape[0]
-            dw = torch.empty_like(w)
-            db = torch.empty(N, dtype=torch.float32, device=w.device) if has_b else None
+            dw = _grad_like(w, ctx.leaf)
+            db = _grad_at(ctx.bias_ptrs[i], (N,), w.device) if has_b else None
             nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
             ws = _ws(nbytes, w.device)
             keep.append(ws)
@@ -207,7 +313,7 @@ class _LinearPair(Function):
             wg[i].rows_per_sample, wg[i].M, wg[i].N, wg[i].K, wg[i].precision = 1, M, N, K, precision()
             grads += [dw, db]
         call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 2, ctypes.cast(jobs, ctypes.c_void_p), st)
-        call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), 2, st)
+        _reduce_jobs(jobs, keep, ctx.leaf)
         return (dx,) + tuple(grads)
 
 
@@ -244,6 +350,8 @@ class _Mlp(Function):
                  M, N, Hd, precision(), f2, stream())
         ctx.save_for_backward(x, w1, w2, pre, act, row_scale)
         ctx.has_res, ctx.rps, ctx.has_b1, ctx.has_b2 = residual is not None, rps, b1 is not None, b2 is not None
+        ctx.leaf = _all_leaf(w1, b1, w2, b2)
+        ctx.bias_ptrs = (_pptr(b1), _pptr(b2)) if ctx.leaf else (0, 0)
         ctx.drop = (float(drop_p), seeds)
         return y
 
@@ -274,15 +382,18 @@ class _Mlp(Function):
             dx = torch.empty_like(x)
             call("cswin_linear_bwd_data", ptr(dpre), ptr(w1), ptr(dx), None, 0, None, None, 1, None, M, Hd, K, precision(), 0, st)
         if True:                                                # both weight gradients
-            dw2 = torch.empty_like(w2)
-            db2 = torch.empty(N, dtype=torch.float32, device=dev) if ctx.has_b2 else None
+            dw2 = _grad_like(w2, ctx.leaf)
+            db2 = _grad_at(ctx.bias_ptrs[1], (N,), dev) if ctx.has_b2 else None
             nbytes = max(lib().cswin_linear_bwd_weight_workspace(M, N, Hd), lib().cswin_linear_bwd_weight_workspace(M, Hd, K))
-            ws = _ws(nbytes, dev)
+            ws, ws1 = _ws(nbytes, dev), _ws(nbytes, dev)
+            jobs = (ReduceJob * 2)()
             call("cswin_linear_bwd_weight", ptr(dyl), ptr(act), None, 0, ptr(rs_gemm), ctx.rps, ptr(dw2), ptr(db2), ptr(ws),
-                 nbytes, M, N, Hd, None, precision(), stream())
-            dw1 = torch.empty_like(w1)
-            db1 = torch.empty(Hd, dtype=torch.float32, device=dev) if ctx.has_b1 else None
-            call("cswin_linear_bwd_weight", ptr(dpre), ptr(x), None, 0, None, 1, ptr(dw1), ptr(db1), ptr(ws), nbytes, M, Hd, K, None, precision(), stream())
+                 nbytes, M, N, Hd, ctypes.cast(ctypes.byref(jobs[0]), ctypes.c_void_p), precision(), stream())
+            dw1 = _grad_like(w1, ctx.leaf)
+            db1 = _grad_at(ctx.bias_ptrs[0], (Hd,), dev) if ctx.has_b1 else None
+            call("cswin_linear_bwd_weight", ptr(dpre), ptr(x), None, 0, None, 1, ptr(dw1), ptr(db1), ptr(ws1), nbytes, M, Hd, K,
+                 ctypes.cast(ctypes.byref(jobs[1]), ctypes.c_void_p), precision(), stream())
+            _reduce_jobs(jobs, (ws, ws1), ctx.leaf)
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None, None, None
 
 
@@ -319,7 +430,10 @@ class _MatmulNN(Function):
         db = torch.empty_like(b)        # db (N, K) = a^T @ dc
         nbytes = lib().cswin_linear_bwd_weight_workspace(M, N, K)
         ws = _ws(nbytes, a.device)
-        call("cswin_linear_bwd_weight", ptr(a), ptr(dc), None, 0, None, 1, ptr(db), None, ptr(ws), nbytes, M, N, K, None, precision(), stream())
+        job = (ReduceJob * 1)()
+        call("cswin_linear_bwd_weight", ptr(a), ptr(dc), None, 0, None, 1, ptr(db), None, ptr(ws), nbytes, M, N, K,
+             ctypes.cast(job, ctypes.c_void_p), precision(), stream())
+        _reduce_jobs(job, (ws,), False)
         return da, db
 
 
@@ -349,6 +463,7 @@ class _StripeAttention(Function):
         call("cswin_attn_fwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(y), ptr(y0), ptr(lse), B, reso, C, nb,
              _int_array(heads), _int_array(idx), split, float(scale or 0.0), drop[0], drop[1], int(q16), stream())
         ctx.save_for_backward(qkv, lse, y0, *ws_, *bs_)
+        ctx.leaf = _all_leaf(*wb)
         ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0), drop)
         return y
 
@@ -363,13 +478,16 @@ class _StripeAttention(Function):
         B, L, C3 = qkv.shape
         C = C3 // 3
         dqkv = torch.empty_like(qkv)
-        dws = [torch.empty_like(w) for w in ws_]
-        dbs = [torch.empty(w.shape[0], dtype=torch.float32, device=qkv.device) for w in ws_]
+        dws = [_grad_like(w, ctx.leaf) for w in ws_]
+        dbs = [_grad_like(b, ctx.leaf) for b in bs_]
         ha, ia = _int_array(heads), _int_array(idx)
         nbytes = lib().cswin_attn_bwd_workspace(B, reso, C, nb, ha, ia, split)
         ws = _ws(nbytes, qkv.device)
+        jobs = (ReduceJob * 2)()
         call("cswin_attn_bwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(lse), ptr(y0), ptr(dy), ptr(dqkv), _ptr_array(dws),
-             _ptr_array(dbs), ptr(ws), nbytes, B, reso, C, nb, ha, ia, split, scale, None, drop[0], drop[1], int(qkv.dtype == torch.bfloat16), stream())
+             _ptr_array(dbs), ptr(ws), nbytes, B, reso, C, nb, ha, ia, split, scale, ctypes.cast(jobs, ctypes.c_void_p), drop[0], drop[1],
+             int(qkv.dtype == torch.bfloat16), stream())
+        _reduce_jobs(jobs, [ws], ctx.leaf)
         return (dqkv, None, None, None, None, None, None) + tuple(d.view(d.shape[0], 1, 3, 3) for d in dws) + tuple(dbs)
 
 
@@ -438,6 +556,8 @@ class _CSWinBlock(Function):
         call("cswin_linear_fwd", ptr(act), None, 0, p2, ptr(bb2), ptr(y), None, ptr(x1), ptr(rs2), L, M, C, Hd, precision(), io_x | f2, st)
         ctx.save_for_backward(x, m1, r1, h1, qkv, lse, att, att0, x1, m2, r2, h2, pre, act, rs1, rs2, g1, wqkv, wp, g2, w1, w2, *lw, *lb)
         ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0), bqkv is not None, s16, drop)
+        ctx.leaf = _all_leaf(g1, b1, wqkv, bqkv, wp, bp, g2, b2, w1, bb1, w2, bb2, *lepe)
+        ctx.bptrs = tuple(_pptr(t) if ctx.leaf else 0 for t in (b1, bqkv, bp, b2, bb1, bb2))     # parameters that are not saved: where their gradients go
         return y
 
     @staticmethod
@@ -478,16 +598,18 @@ class _CSWinBlock(Function):
             wg[slot].workspace, wg[slot].ws_bytes = wsp[wsi].value, sizes[wsi]
             wg[slot].rows_per_sample, wg[slot].M, wg[slot].N, wg[slot].K, wg[slot].precision = L, M, N_, K_, precision()
 
-        dw2, db2 = torch.empty_like(w2), E(C)
+        pb1, pbqkv, pbp, pb2, pbb1, pbb2 = ctx.bptrs
+        leaf = ctx.leaf
+        dw2, db2 = _grad_like(w2, leaf), _grad_at(pbb2, (C,), dev)
         if dy16 is not None:
             defer_wgrad(0, dy16, act, rs2, dw2, db2, 0, C, Hd, io=3)   # dy's twin and x = act are stored as bf16
         else:
             defer_wgrad(0, dy, act, rs2, dw2, db2, 0, C, Hd, io=2)     # x = act is stored as bf16
-        dw1, db1 = torch.empty_like(w1), E(Hd)
+        dw1, db1 = _grad_like(w1, leaf), _grad_at(pbb1, (Hd,), dev)
         defer_wgrad(1, dpre, h2, None, dw1, db1, 1, Hd, C, io=3)        # dy = dpre and x = h2 are stored as bf16
         dh2 = torch.empty_like(x)                                      # fp32 (x is)
         call("cswin_linear_bwd_data", ptr(dpre), p1, ptr(dh2), None, 0, None, None, 1, None, M, Hd, C, precision(), (1 if s16 else 0) | f1, st)
-        dx1, dg2, dbt2 = torch.empty_like(x), E(C), E(C)
+        dx1, dg2, dbt2 = torch.empty_like(x), _grad_like(g2, leaf), _grad_at(pb2, (C,), dev)
         dx1_16 = E16(B, L, C) if s16 else None                         # the GEMMs below read the twin, the residual path dx1
         call("cswin_layernorm_bwd", ptr(dh2), ptr(x1), ptr(m2), ptr(r2), ptr(g2), ptr(dy), ptr(dx1), ptr(dg2), ptr(dbt2), wsp[2],
              sizes[2], M, C, J(2), ptr(dx1_16), st)
@@ -495,18 +617,18 @@ class _CSWinBlock(Function):
         datt = dh2                                                     # reuse
         call("cswin_linear_bwd_data", ptr(dx1_16 if s16 else dx1), pp, ptr(datt), None, 0, None, ptr(rs1), L, None, M, C, C, precision(),
              fp | (1 if s16 else 0), st)
-        dwp, dbp = torch.empty_like(wp), E(C)
+        dwp, dbp = _grad_like(wp, leaf), _grad_at(pbp, (C,), dev)
         defer_wgrad(2, dx1_16 if s16 else dx1, att, rs1, dwp, dbp, 3, C, C, io=3)      # dx1's twin and x = att are stored as bf16
         dqkv = torch.empty_like(qkv)
-        dlw = [torch.empty_like(t) for t in lw]
-        dlb = [E(t.shape[0]) for t in lw]
+        dlw = [_grad_like(t, leaf) for t in lw]
+        dlb = [_grad_like(t, leaf) for t in lb]
         ha, ia = _int_array(heads), _int_array(idx)
         naw = h.cswin_attn_bwd_workspace(B, reso, C, nb, ha, ia, split)
         aws = _ws(naw, dev)
         call("cswin_attn_bwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(lse), ptr(att0), ptr(datt), ptr(dqkv),
              _ptr_array(dlw), _ptr_array(dlb), ptr(aws), naw, B, reso, C, nb, ha, ia, split, scale, J(6), drop[0], drop[1], 7 if s16 else 0, st)
-        dwqkv = torch.empty_like(wqkv)
-        dbqkv = E(3 * C) if has_qkv_bias else None
+        dwqkv = _grad_like(wqkv, leaf)
+        dbqkv = _grad_at(pbqkv, (3 * C,), dev) if has_qkv_bias else None
         defer_wgrad(3, dqkv, h1, None, dwqkv, dbqkv, 4, 3 * C, C, io=3)  # dy = dqkv and x = h1 are stored as bf16
         wjobs = (ReduceJob * 4)()
         call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(wjobs, ctypes.c_void_p), st)
@@ -514,13 +636,13 @@ class _CSWinBlock(Function):
             jobs[ji] = wjobs[slot]
         dh1 = datt                                                     # reuse again
         call("cswin_linear_bwd_data", ptr(dqkv), pq, ptr(dh1), None, 0, None, None, 1, None, M, 3 * C, C, precision(), (1 if s16 else 0) | fq, st)
-        dx, dg1, dbt1 = torch.empty_like(x), E(C), E(C)
+        dx, dg1, dbt1 = torch.empty_like(x), _grad_like(g1, leaf), _grad_at(pb1, (C,), dev)
         dx16 = E16(B, L, C) if s16 else None
         call("cswin_layernorm_bwd", ptr(dh1), ptr(x), ptr(m1), ptr(r1), ptr(g1), ptr(dx1), ptr(dx), ptr(dg1), ptr(dbt1), wsp[5],
              sizes[5], M, C, J(5), ptr(dx16), st)
         if s16:
             _twin_put(dx, dx16)
-        call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), 6 + nb, st)
+        _reduce_jobs(jobs, [ws, aws], leaf)
         grads = (dx, None, None, None, None, None, None, None, None, None, None, dg1, dbt1, dwqkv, dbqkv, dwp, dbp, dg2, dbt2, dw1, db1,
                  dw2, db2)
         return grads + tuple(d.view(d.shape[0], 1, 3, 3) for d in dlw) + tuple(dlb)
@@ -561,6 +683,8 @@ class _ConvTokens(Function):
         call("cswin_conv_tok_fwd", ptr(x), ptr(wp), ptr(b), ptr(y), B, H, W, Cin, Cout, ks, stride, pad, precision(), stream())
         ctx.save_for_backward(x, w, wpt)
         ctx.meta = (H, W, stride, pad, b is not None)
+        ctx.leaf = _all_leaf(w, b)
+        ctx.bias_ptr = _pptr(b) if ctx.leaf else 0
         return y
 
     @staticmethod
@@ -586,12 +710,14 @@ class _ConvTokens(Function):
                     _, wpt = _permute_w(w, Cin, True)
                 call("cswin_conv_tok_bwd_data", ptr(dy), ptr(wpt), ptr(dx), B, H, W, Cin, Cout, ks, stride, pad, precision(), st)
         if True:
-            dw = torch.empty_like(w)                    # written in the parameter layout by the slab reduction itself
-            db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_b else None
+            dw = _grad_like(w, ctx.leaf)                # written in the parameter layout by the slab reduction itself
+            db = _grad_at(ctx.bias_ptr, (Cout,), x.device) if has_b else None
             nbytes = lib().cswin_conv_tok_bwd_weight_workspace(B, H, W, Cin, Cout, ks, stride, pad)
             ws = _ws(nbytes, x.device)
+            job = (ReduceJob * 1)()
             call("cswin_conv_tok_bwd_weight", ptr(dy), ptr(x), ptr(dw), ptr(db), ptr(ws), nbytes, B, H, W, Cin, Cout, ks,
-                 stride, pad, 1, precision(), stream())
+                 stride, pad, 1, ctypes.cast(job, ctypes.c_void_p), precision(), stream())
+            _reduce_jobs(job, (ws,), ctx.leaf)
         return dx, dw, db, None, None, None, None
 
 
@@ -618,6 +744,8 @@ class _PatchEmbedConv(Function):
         call("cswin_conv_tok_fwd", ptr(x), ptr(wp), ptr(b), ptr(y), B, H, W, cpad, Cout, ks, stride, pad, precision(), st)
         ctx.save_for_backward(x, w)
         ctx.meta = (H, W, stride, pad, cpad, b is not None)
+        ctx.leaf = _all_leaf(w, b)
+        ctx.bias_ptr = _pptr(b) if ctx.leaf else 0
         return y
 
     @staticmethod
@@ -630,12 +758,12 @@ class _PatchEmbedConv(Function):
         Cout, Cin, ks, _ = w.shape
         st = stream()
         dwp = torch.empty(Cout, ks * ks, cpad, dtype=torch.float32, device=x.device)
-        db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_b else None
+        db = _grad_at(ctx.bias_ptr, (Cout,), x.device) if has_b else None
         nbytes = lib().cswin_conv_tok_bwd_weight_workspace(B, H, W, cpad, Cout, ks, stride, pad)
         ws = _ws(nbytes, x.device)
         call("cswin_conv_tok_bwd_weight", ptr(dy), ptr(x), ptr(dwp), ptr(db), ptr(ws), nbytes, B, H, W, cpad, Cout, ks, stride,
-             pad, 0, precision(), st)                                # channel-padded image (3 -> 4): unpermuted separately
-        dw = torch.empty_like(w)
+             pad, 0, None, precision(), st)                          # channel-padded image (3 -> 4): unpermuted separately, right away
+        dw = _grad_like(w, ctx.leaf)
         call("cswin_conv_weight_unpermute", ptr(dwp), ptr(dw), Cout, Cin, ks, cpad, st)
         return None, dw, db, None, None
 
@@ -658,6 +786,7 @@ class _CarafeReassemble(Function):
         call("cswin_carafe_fwd", ptr(e), ptr(z), ptr(bias), ptr(out), ptr(wt), B, H, W, Cz, S, stream())
         ctx.save_for_backward(z, wt)
         ctx.meta = (H, W, S, bias is not None)
+        ctx.bias_ptr = _pptr(bias) if _all_leaf(bias) else 0
         return out
 
     @staticmethod
@@ -669,7 +798,7 @@ class _CarafeReassemble(Function):
         B, L, Cz = z.shape
         de = torch.empty_like(wt)
         dz = torch.empty_like(z)
-        db = torch.empty(Cz, dtype=torch.float32, device=z.device) if has_b else None
+        db = _grad_at(ctx.bias_ptr, (Cz,), z.device) if has_b else None
         nbytes = lib().cswin_carafe_bwd_workspace(B, H, W, Cz, S)
         ws = _ws(nbytes, z.device)
         call("cswin_carafe_bwd", ptr(dout), ptr(z), ptr(wt), ptr(de), ptr(dz), ptr(db), ptr(ws), nbytes, B, H, W, Cz, S, stream())

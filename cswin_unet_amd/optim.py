@@ -73,11 +73,17 @@ class FlatSGD:
             for p, o, src in zip(self.params[first:last], self.offsets[first:last], key):
                 if src == 0:
                     raise RuntimeError("FlatSGD.step(): a parameter has no gradient")
+                if src == base + 4 * o:
+                    continue                          # written in place (ops.engine_backward): nothing to pack
                 if not p.grad.is_contiguous():
                     raise RuntimeError("FlatSGD.step(): non-contiguous gradient")
                 n = p.numel()
                 for c in range(0, n, _CHUNK):
                     rows.append((src + 4 * c, base + 4 * (o + c), min(_CHUNK, n - c)))
+            slot["empty"] = not rows
+            if not rows:
+                slot["key"] = key
+                return None
             if "host" not in slot:
                 # pinned host side allocated once per range (outside any capture: the first call is an eager warm-up)
                 slot["host"] = torch.zeros(len(rows), 3, dtype=torch.int64).pin_memory()
@@ -88,7 +94,7 @@ class FlatSGD:
             # async upload from pinned memory: a memcpy node when captured (the host buffer lives with the optimiser)
             slot["dev"].copy_(slot["host"], non_blocking=True)
             slot["key"] = key
-        return slot["dev"]
+        return None if slot.get("empty") else slot["dev"]
 
     def gather_grads(self, first=0, last=None):
         """Pack p.grad of parameters first..last-1 into self.flat_grad (one launch)."""
@@ -96,7 +102,8 @@ class FlatSGD:
         join_wgrad_stream()          # weight gradients may have been produced on the side stream
         last = len(self.params) if last is None else last
         t = self._gather_table(first, last)
-        call("cswin_multi_copy", ptr(t), t.shape[0], stream())
+        if t is not None:
+            call("cswin_multi_copy", ptr(t), t.shape[0], stream())
         return self.flat_grad
 
     def apply(self, grad_scale=1.0):

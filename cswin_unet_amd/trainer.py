@@ -134,13 +134,18 @@ class HipEngine:
         dlogits = self._loss_grad(logits, lab, dice_grad_scale)
         params, n_enc = self.opt.params, self.n_enc
         self.opt.zero_grad()
+        from .ops import engine_backward
         if not self.split_backward:
-            logits.backward(dlogits)
+            with engine_backward(self.opt):
+                grads = torch.autograd.grad([logits], params, [dlogits])
+            for p, g in zip(params, grads):
+                p.grad = g
             self.opt.gather_grads()
             return None
         core = self.core
         dec_in = list(core.dec_in)                    # detached leaves the decoder consumed (detach_decoder_inputs)
-        grads = torch.autograd.grad([logits], params[n_enc:] + dec_in, [dlogits])
+        with engine_backward(self.opt):
+            grads = torch.autograd.grad([logits], params[n_enc:] + dec_in, [dlogits])
         for p, g in zip(params[n_enc:], grads):
             p.grad = g
         self.opt.gather_grads(n_enc, len(params))
@@ -152,7 +157,9 @@ class HipEngine:
         (xb, x1, x2, x3), (dxb, dx1, dx2, dx3) = boundary
         params, lo, hi = self.opt.params, self.n_mid, self.n_enc
         mid = self.core.enc_mid_in
-        grads = torch.autograd.grad([xb, x3], params[lo:hi] + [mid], [dxb, dx3])
+        from .ops import engine_backward
+        with engine_backward(self.opt):
+            grads = torch.autograd.grad([xb, x3], params[lo:hi] + [mid], [dxb, dx3])
         for p, g in zip(params[lo:hi], grads):
             p.grad = g
         self.opt.gather_grads(lo, hi)
@@ -162,7 +169,9 @@ class HipEngine:
         bound, dbound = boundary
         params = self.opt.params
         hi = self.n_enc if hi is None else hi
-        grads = torch.autograd.grad(bound, params[lo:hi], dbound)
+        from .ops import engine_backward
+        with engine_backward(self.opt):
+            grads = torch.autograd.grad(bound, params[lo:hi], dbound)
         for p, g in zip(params[lo:hi], grads):
             p.grad = g
         self.opt.gather_grads(lo, hi)

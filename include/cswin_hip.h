@@ -38,14 +38,18 @@ extern "C" {
 #define CSWIN_ERR_HIP (-4)
 #define CSWIN_ERR_UNSUPPORTED (-5)
 
-/* A slab reduction left pending by a producer called with `deferred` != NULL; batch up to 8 of them into one launch with
- * cswin_rows_sum_multi (a CSWinBlock backward has six: four weight gradients, two LayerNorm dgamma/dbeta). */
+/* A slab reduction left pending by a producer called with `deferred` != NULL; batch up to 48 of them into one launch with
+ * cswin_rows_sum_multi (a CSWinBlock backward has six to eight: four weight gradients, two LayerNorm dgamma/dbeta, the LePE conv
+ * gradients; cswin_unet_amd.ops queues the jobs of a whole backward pass and reduces them in one or two launches).
+ * conv_kk / conv_cin != 0: columns [0, n_first) are a convolution weight gradient in the implicit-GEMM order [Cout][k*k][Cin] and
+ * are stored to `out` in the nn.Conv2d order [Cout][Cin][k][k]. */
 typedef struct cswin_reduce_job {
     const float* part;
     float* out;
     float* out2;
     long long n_first, n, stride;
     int rows, reserved;
+    int conv_kk, conv_cin;
 } cswin_reduce_job;
 
 const char* cswin_last_error(void);
@@ -152,7 +156,7 @@ typedef struct cswin_wgrad_desc {
 /* Up to 4 independent weight gradients (the four nn.Linear of a CSWinBlock, cswin_unet.py:125,134,17-19) in ONE launch;
  * deferred[0..n) receive their slab reductions (required: run them with cswin_rows_sum_multi). */
 int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* problems, int n, cswin_reduce_job* deferred, void* stream);
-/* jobs: host array of 1..8 pending reductions (the workspaces they point into must still be alive) */
+/* jobs: host array of 1..48 pending reductions (the workspaces they point into must still be alive) */
 int cswin_rows_sum_multi(const cswin_reduce_job* jobs, int njobs, void* stream);
 
 /* ---- convolutions on tokens (NHWC) as implicit GEMM: stage1_conv_embed 7x7 s4 p2 (cswin_unet.py:339),
@@ -165,10 +169,11 @@ int cswin_conv_tok_bwd_data(const float* dy, const float* w_permT, float* dx, in
                             int ks, int stride, int pad, int precision, void* stream);
 size_t cswin_conv_tok_bwd_weight_workspace(int B, int H, int W, int Cin, int Cout, int ks, int stride, int pad);
 /* dw: [Cout][ks*ks][Cin] (torch_layout 0, the image cswin_conv_weight_unpermute takes) or directly the nn.Conv2d parameter
- * layout [Cout][Cin][ks][ks] (torch_layout 1: the slab reduction writes it, no separate unpermute launch) */
+ * layout [Cout][Cin][ks][ks] (torch_layout 1: the slab reduction writes it, no separate unpermute launch).  deferred: NULL, or
+ * the slot that receives the slab reduction instead of its launch (as for the Linear weight gradients). */
 int cswin_conv_tok_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, void* workspace,
                               size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ks, int stride, int pad,
-                              int torch_layout, int precision, void* stream);
+                              int torch_layout, cswin_reduce_job* deferred, int precision, void* stream);
 /* w [Cout][Cin][ks][ks] -> w_perm [Cout][ks*ks][Cpad] and/or w_permT [ks*ks][Cout][Cpad] (zero padded channels) */
 int cswin_conv_weight_permute(const float* w, float* w_perm, float* w_permT, int Cout, int Cin, int ks, int Cpad,
                               void* stream);
