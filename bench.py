@@ -91,9 +91,9 @@ def attention_roofline(batch, cfg, img_size=224, bf16=False):
         nbytes = lib().cswin_attn_bwd_workspace(batch, reso, C, nb, ha, ia, split[si])
         ws = torch.empty(nbytes // 4 + 4, device=dev)
         t_f = _graph_time(lambda: call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(y0), ptr(lse), batch, reso, C, nb, ha, ia,
-                                       split[si], 0.0, 0.0, 0, mode, stream()))
+                                       split[si], 0.0, 0.0, 0, None, mode, stream()))
         t_b = _graph_time(lambda: call("cswin_attn_bwd", ptr(qkv), pa(w), pa(b), ptr(lse), ptr(y0), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws),
-                                       nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, None, 0.0, 0, mode, stream()))
+                                       nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, None, 0.0, 0, None, mode, stream()))
         flops_f = 4.0 * L * n_tok * C * batch
         n_blocks = 2 * depth[si]
         bytes_f, bytes_b = 16.0 * L * C * batch, 28.0 * L * C * batch

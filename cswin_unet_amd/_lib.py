@@ -22,9 +22,9 @@ SIGNATURES = {
     "cswin_last_error": (c_char_p, []),
     "cswin_abi_version": (I, []),
     "cswin_device_ok": (I, []),
-    "cswin_attn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, P, P, I, F, F, ctypes.c_ulonglong, I, P]),
+    "cswin_attn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, P, P, I, F, F, ctypes.c_ulonglong, P, I, P]),
     "cswin_attn_bwd_workspace": (SZ, [I, I, I, I, P, P, I]),
-    "cswin_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, I, I, P, P, I, F, P, F, ctypes.c_ulonglong, I, P]),
+    "cswin_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, I, I, P, P, I, F, P, F, ctypes.c_ulonglong, P, I, P]),
     "cswin_img2windows": (I, [P, P, I, I, I, I, I, I, P]),
     "cswin_windows2img": (I, [P, P, I, I, I, I, I, I, P]),
     "cswin_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, I, P]),
@@ -52,7 +52,7 @@ SIGNATURES = {
     "cswin_loss_sums": (I, [P, P, P, P, SZ, I, I, L, I, P]),
     "cswin_loss_finalize": (I, [P, P, P, D, I, F, F, P, P]),
     "cswin_loss_bwd": (I, [P, P, P, P, P, F, F, I, I, L, I, P]),
-    "cswin_dropout": (I, [P, P, P, P, L, L, F, ctypes.c_ulonglong, P]),
+    "cswin_dropout": (I, [P, P, P, P, L, L, F, ctypes.c_ulonglong, P, P]),
     "cswin_sgd_flat": (I, [P, P, P, L, P, F, F, F, P, P]),
     "cswin_multi_copy": (I, [P, I, P]),
     "cswin_pack_bf16": (I, [P, P, L, P]),

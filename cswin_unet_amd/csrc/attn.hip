@@ -61,6 +61,7 @@ struct AttnParams {
     float drop_p, drop_scale;   // attention-probability dropout (cswin_unet.py:101): p (0 = off) and 1 / (1 - p)
     unsigned drop_thresh;       // keep iff 24 hash bits >= p * 2^24
     unsigned long long drop_seed;
+    const unsigned long long* drop_epoch;   // device-resident step counter added to drop_seed (NULL: none)
     int nbranch;
     int ds_stride;         // fused backward: LDS row stride of the dS image (>= N, = 4 mod 8: conflict-free column writes)
     int slab_rows;         // LePE gradient slab rows per window (1 on every current path)
@@ -125,7 +126,7 @@ __device__ __forceinline__ long attn_unit_id(const AttnParams& p, const AttnBran
 }
 __device__ __forceinline__ float attn_keep(const AttnParams& p, long uid, int N, int tq, int tk) {
     const unsigned long long i = ((unsigned long long)uid * (unsigned)N + (unsigned)tq) * (unsigned)N + (unsigned)tk;
-    const unsigned long long r = attn_mix64(attn_mix64(p.drop_seed) ^ i);
+    const unsigned long long r = attn_mix64(attn_mix64(p.drop_seed + (p.drop_epoch ? *p.drop_epoch : 0ull)) ^ i);
     return (unsigned)(r >> 40) >= p.drop_thresh ? p.drop_scale : 0.f;
 }
 
@@ -1651,10 +1652,10 @@ void cswin_debug_set_attn_stamps(void* p) { g_attn_stamps = (long long*)p; }
 // [i*C/2, (i+1)*C/2) with stripe mode idx[i]; nbranch = 1: whole C, idx[0] (normally -1).
 int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, float* y, float* y0, float* lse,
                    int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split, float scale, float drop_p,
-                   unsigned long long drop_seed, int qkv_bf16, void* stream) {
+                   unsigned long long drop_seed, const unsigned long long* drop_epoch, int qkv_bf16, void* stream) {
     AttnParams p = {};
     CSWIN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, CSWIN_ERR_UNSUPPORTED, "attn_fwd: dropout probability %g outside [0, 1)", (double)drop_p);
-    p.drop_p = drop_p; p.drop_scale = 1.0f / (1.0f - drop_p); p.drop_thresh = (unsigned)(drop_p * 16777216.0f); p.drop_seed = drop_seed;
+    p.drop_p = drop_p; p.drop_scale = 1.0f / (1.0f - drop_p); p.drop_thresh = (unsigned)(drop_p * 16777216.0f); p.drop_seed = drop_seed; p.drop_epoch = drop_epoch;
     CSWIN_REQUIRE(qkv_bf16 == 0 || qkv_bf16 == 1 || qkv_bf16 == 3 || qkv_bf16 == 7, CSWIN_ERR_UNSUPPORTED,
                   "attn: mode %d (0 = fp32, 1 = qkv / dqkv stored as bf16, 3 = also y, 7 = also bf16 MFMAs)", qkv_bf16);
     p.qkv_bf16 = qkv_bf16;
@@ -1697,11 +1698,11 @@ size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* 
 int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, const float* lse,
                    const float* y0, const float* dy, float* dqkv, float* const* dlepe_w, float* const* dlepe_b,
                    void* workspace, size_t ws_bytes, int B, int reso, int C, int nbranch, const int* heads, const int* idx,
-                   int split, float scale, cswin_reduce_job* deferred, float drop_p, unsigned long long drop_seed, int qkv_bf16,
-                   void* stream) {
+                   int split, float scale, cswin_reduce_job* deferred, float drop_p, unsigned long long drop_seed,
+                   const unsigned long long* drop_epoch, int qkv_bf16, void* stream) {
     AttnParams p = {};
     CSWIN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, CSWIN_ERR_UNSUPPORTED, "attn_bwd: dropout probability %g outside [0, 1)", (double)drop_p);
-    p.drop_p = drop_p; p.drop_scale = 1.0f / (1.0f - drop_p); p.drop_thresh = (unsigned)(drop_p * 16777216.0f); p.drop_seed = drop_seed;
+    p.drop_p = drop_p; p.drop_scale = 1.0f / (1.0f - drop_p); p.drop_thresh = (unsigned)(drop_p * 16777216.0f); p.drop_seed = drop_seed; p.drop_epoch = drop_epoch;
     CSWIN_REQUIRE(qkv_bf16 == 0 || qkv_bf16 == 1 || qkv_bf16 == 3 || qkv_bf16 == 7, CSWIN_ERR_UNSUPPORTED,
                   "attn: mode %d (0 = fp32, 1 = qkv / dqkv stored as bf16, 3 = also y, 7 = also bf16 MFMAs)", qkv_bf16);
     p.qkv_bf16 = qkv_bf16;

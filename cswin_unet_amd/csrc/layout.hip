@@ -92,7 +92,9 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
 
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, const float* __restrict__ residual,
                                                        const float* __restrict__ row_scale, float* __restrict__ y, long n,
-                                                       long elems_per_sample, float p, unsigned long long seed) {
+                                                       long elems_per_sample, float p, unsigned long long seed,
+                                                       const unsigned long long* __restrict__ epoch) {
+    if (epoch) seed += *epoch;                                 // device-resident step counter: a replayed hipGraph draws a new mask
     const unsigned thr = (unsigned)(p * 65536.0f);             // keep iff u16 >= thr  (P(drop) = thr / 65536)
     const float inv_keep = 1.0f / (1.0f - p);
     const long n4 = n / 4;
@@ -112,14 +114,14 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 extern "C" {
 
 int cswin_dropout(const float* x, const float* residual, const float* row_scale, float* y, long n, long elems_per_sample,
-                  float p, unsigned long long seed, void* stream) {
+                  float p, unsigned long long seed, const unsigned long long* seed_epoch, void* stream) {
     CSWIN_REQUIRE(x && y && n > 0 && n % 4 == 0 && elems_per_sample > 0 && elems_per_sample % 4 == 0, CSWIN_ERR_SHAPE,
                   "dropout: n and elems_per_sample must be positive multiples of 4");
     CSWIN_REQUIRE(p >= 0.f && p < 1.f, CSWIN_ERR_SHAPE, "dropout: p = %f outside [0, 1)", p);
     CSWIN_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)residual)) & 15) == 0, CSWIN_ERR_ALIGN, "dropout: 16-B alignment required");
     long b = (n / 4 + 255) / 256;
     hipLaunchKernelGGL(dropout_kernel, dim3((int)(b > 8192 ? 8192 : b)), dim3(256), 0, (hipStream_t)stream, x, residual, row_scale, y, n,
-                       elems_per_sample, p, seed);
+                       elems_per_sample, p, seed, seed_epoch);
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }

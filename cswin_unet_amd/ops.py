@@ -341,10 +341,9 @@ class _Mlp(Function):
         y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
         rps = _rows_per_sample(x) if row_scale is not None else 1
         if drop_p > 0:
-            call("cswin_dropout", ptr(act), None, None, ptr(act), act.numel(), act.numel() // act.shape[0], drop_p, seeds[0], stream())
+            call("cswin_dropout", ptr(act), None, None, ptr(act), act.numel(), act.numel() // act.shape[0], drop_p, seeds[0], ptr(dropout_epoch(act.device)), stream())
             call("cswin_linear_fwd", ptr(act), None, 0, p2, ptr(b2), ptr(y), None, None, None, 1, M, N, Hd, precision(), f2, stream())
-            call("cswin_dropout", ptr(y), ptr(residual), ptr(row_scale), ptr(y), y.numel(), y.numel() // y.shape[0], drop_p, seeds[1],
-                 stream())
+            call("cswin_dropout", ptr(y), ptr(residual), ptr(row_scale), ptr(y), y.numel(), y.numel() // y.shape[0], drop_p, seeds[1], ptr(dropout_epoch(y.device)), stream())
         else:
             call("cswin_linear_fwd", ptr(act), None, 0, p2, ptr(b2), ptr(y), None, ptr(residual), ptr(row_scale), rps,
                  M, N, Hd, precision(), f2, stream())
@@ -369,14 +368,14 @@ class _Mlp(Function):
         dyl, rs_gemm = dy, row_scale                 # gradient of fc2's output, and the row factor still to be applied by the GEMMs
         if drop_p > 0:
             dyl = torch.empty_like(dy)
-            call("cswin_dropout", ptr(dy), None, ptr(row_scale), ptr(dyl), dy.numel(), dy.numel() // dy.shape[0], drop_p, seeds[1], st)
+            call("cswin_dropout", ptr(dy), None, ptr(row_scale), ptr(dyl), dy.numel(), dy.numel() // dy.shape[0], drop_p, seeds[1], ptr(dropout_epoch(dy.device)), st)
             rs_gemm = None
         # d pre = (row_scale * dy @ w2) * gelu'(pre)   (GELU backward fused into the data-gradient epilogue)
         dpre = torch.empty_like(pre)
         call("cswin_linear_bwd_data", ptr(dyl), ptr(w2), ptr(dpre), None, 0, ptr(pre), ptr(rs_gemm), ctx.rps, None, M, N,
              Hd, precision(), 0, st)
         if drop_p > 0:
-            call("cswin_dropout", ptr(dpre), None, None, ptr(dpre), dpre.numel(), dpre.numel() // dpre.shape[0], drop_p, seeds[0], st)
+            call("cswin_dropout", ptr(dpre), None, None, ptr(dpre), dpre.numel(), dpre.numel() // dpre.shape[0], drop_p, seeds[0], ptr(dropout_epoch(dpre.device)), st)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -395,6 +394,24 @@ class _Mlp(Function):
                  ctypes.cast(ctypes.byref(jobs[1]), ctypes.c_void_p), precision(), stream())
             _reduce_jobs(jobs, (ws, ws1), ctx.leaf)
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None, None, None
+
+
+# Device-resident dropout epoch: every dropout launch adds its value to the seed it was given.  The seed itself comes from the host
+# generator when the op is called -- under hipGraph replay that is ONCE, at capture -- so the engine advances this counter by one
+# kernel inside the captured step and every replay draws fresh masks (forward and backward of one step see the same value).
+_epoch = {}
+
+
+def dropout_epoch(device):
+    t = _epoch.get(device)
+    if t is None:
+        t = _epoch[device] = torch.zeros(1, dtype=torch.int64, device=device)
+    return t
+
+
+def advance_dropout_epoch(device):
+    """epoch += 1 on the current stream (capturable)."""
+    dropout_epoch(device).add_(1)
 
 
 def _draw_seeds(n):
@@ -461,7 +478,8 @@ class _StripeAttention(Function):
         y0 = torch.empty_like(y) if any(ctx.needs_input_grad) else None          # P V without LePE: the backward's delta term
         lse = torch.empty(B, sum(heads), L, dtype=torch.float32, device=qkv.device)
         call("cswin_attn_fwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(y), ptr(y0), ptr(lse), B, reso, C, nb,
-             _int_array(heads), _int_array(idx), split, float(scale or 0.0), drop[0], drop[1], int(q16), stream())
+             _int_array(heads), _int_array(idx), split, float(scale or 0.0), drop[0], drop[1], ptr(dropout_epoch(qkv.device)) if drop[0] > 0 else None,
+             int(q16), stream())
         ctx.save_for_backward(qkv, lse, y0, *ws_, *bs_)
         ctx.leaf = _all_leaf(*wb)
         ctx.meta = (reso, split, tuple(idx), tuple(heads), float(scale or 0.0), drop)
@@ -486,7 +504,7 @@ class _StripeAttention(Function):
         jobs = (ReduceJob * 2)()
         call("cswin_attn_bwd", ptr(qkv), _ptr_array(ws_), _ptr_array(bs_), ptr(lse), ptr(y0), ptr(dy), ptr(dqkv), _ptr_array(dws),
              _ptr_array(dbs), ptr(ws), nbytes, B, reso, C, nb, ha, ia, split, scale, ctypes.cast(jobs, ctypes.c_void_p), drop[0], drop[1],
-             int(qkv.dtype == torch.bfloat16), stream())
+             ptr(dropout_epoch(qkv.device)) if drop[0] > 0 else None, int(qkv.dtype == torch.bfloat16), stream())
         _reduce_jobs(jobs, [ws], ctx.leaf)
         return (dqkv, None, None, None, None, None, None) + tuple(d.view(d.shape[0], 1, 3, 3) for d in dws) + tuple(dbs)
 
@@ -544,7 +562,7 @@ class _CSWinBlock(Function):
         att0 = E16(B, L, C) if any(ctx.needs_input_grad) else None       # P V without LePE: the attention backward's delta term
         ha, ia = _int_array(heads), _int_array(idx)
         call("cswin_attn_fwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(att), ptr(att0), ptr(lse), B, reso, C, nb, ha, ia, split,
-             float(scale or 0.0), drop[0], drop[1], 7 if s16 else 0, st)
+             float(scale or 0.0), drop[0], drop[1], ptr(dropout_epoch(dev)) if drop[0] > 0 else None, 7 if s16 else 0, st)
         x1 = torch.empty_like(x)
         call("cswin_linear_fwd", ptr(att), None, 0, pp, ptr(bp), ptr(x1), None, ptr(x), ptr(rs1), L, M, C, C, precision(), io_x | fp, st)
         h2, m2, r2 = E16(B, L, C), E(M), E(M)
@@ -626,7 +644,8 @@ class _CSWinBlock(Function):
         naw = h.cswin_attn_bwd_workspace(B, reso, C, nb, ha, ia, split)
         aws = _ws(naw, dev)
         call("cswin_attn_bwd", ptr(qkv), _ptr_array(lw), _ptr_array(lb), ptr(lse), ptr(att0), ptr(datt), ptr(dqkv),
-             _ptr_array(dlw), _ptr_array(dlb), ptr(aws), naw, B, reso, C, nb, ha, ia, split, scale, J(6), drop[0], drop[1], 7 if s16 else 0, st)
+             _ptr_array(dlw), _ptr_array(dlb), ptr(aws), naw, B, reso, C, nb, ha, ia, split, scale, J(6), drop[0], drop[1],
+             ptr(dropout_epoch(dev)) if drop[0] > 0 else None, 7 if s16 else 0, st)
         dwqkv = _grad_like(wqkv, leaf)
         dbqkv = _grad_at(pbqkv, (3 * C,), dev) if has_qkv_bias else None
         defer_wgrad(3, dqkv, h1, None, dwqkv, dbqkv, 4, 3 * C, C, io=3)  # dy = dqkv and x = h1 are stored as bf16
@@ -923,7 +942,7 @@ class _Dropout(Function):
         x, residual, row_scale = dev_f32(x, "dropout input"), dev_f32(residual), dev_f32(row_scale)
         y = torch.empty_like(x)
         eps = x.numel() // x.shape[0]
-        call("cswin_dropout", ptr(x), ptr(residual), ptr(row_scale), ptr(y), x.numel(), eps, float(p), int(seed), stream())
+        call("cswin_dropout", ptr(x), ptr(residual), ptr(row_scale), ptr(y), x.numel(), eps, float(p), int(seed), ptr(dropout_epoch(x.device)), stream())
         ctx.save_for_backward(row_scale)
         ctx.meta = (float(p), int(seed), eps, residual is not None)
         return y
@@ -935,7 +954,7 @@ class _Dropout(Function):
         p, seed, eps, has_res = ctx.meta
         dy = dev_f32(dy)
         dx = torch.empty_like(dy)
-        call("cswin_dropout", ptr(dy), None, ptr(row_scale), ptr(dx), dy.numel(), eps, p, seed, stream())
+        call("cswin_dropout", ptr(dy), None, ptr(row_scale), ptr(dx), dy.numel(), eps, p, seed, ptr(dropout_epoch(dy.device)), stream())
         return dx, (dy if has_res else None), None, None, None
 
 

@@ -90,12 +90,10 @@ class HipEngine:
         self.sums = torch.zeros(1 + 3 * num_classes, dtype=torch.float32, device=dev)
         self.stats = torch.zeros(3, dtype=torch.float32, device=dev)          # [loss, ce, dice] of the last step
         self._coef = torch.zeros(2 * num_classes, dtype=torch.float32, device=dev)
-        # nn.Dropout with p > 0 (no reference config has one): the dropout kernels take their seeds from the HOST generator at
-        # launch time, so a captured graph would replay one frozen mask every step -- such models run eagerly
-        if use_graph and any(isinstance(m, torch.nn.Dropout) and m.p > 0 for m in model.modules()):
-            import warnings
-            warnings.warn("HipEngine: model has live nn.Dropout (p > 0); hipGraph replay would freeze its masks, running eagerly")
-            use_graph = False
+        # nn.Dropout with p > 0 (no reference config has one): the dropout kernels take their seeds from the HOST generator when the op
+        # is called -- once, at capture, for a replayed graph -- and add the device-resident epoch counter (ops.dropout_epoch) to
+        # them; the step advances that counter by one kernel inside graph A, so every replay draws fresh masks
+        self._live_dropout = any(isinstance(m, torch.nn.Dropout) and m.p > 0 for m in model.modules())
         self.use_graph, self._graphs, self._logits = use_graph, None, None
         self._wire = {}
 
@@ -113,6 +111,9 @@ class HipEngine:
 
     # ---- eager pieces -------------------------------------------------------------------------------------------
     def _forward_sums(self, img, lab):
+        if self._live_dropout:
+            from .ops import advance_dropout_epoch
+            advance_dropout_epoch(img.device)           # inside graph A when captured: a new mask set per replayed step
         logits = self.model(img)
         B, ncls = logits.shape[:2]
         hw = logits.numel() // (B * ncls)

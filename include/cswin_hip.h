@@ -75,10 +75,12 @@ int cswin_device_ok(void); /* 1 if the current HIP device is gfx950 */
  * lse (B, sum(heads), L): row log-sum-exp saved for backward.  scale <= 0 selects head_dim^-0.5 (:42). */
 int cswin_attn_fwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, float* y, float* y0, float* lse,
                    int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split, float scale,
-                   float drop_p, unsigned long long drop_seed, int qkv_bf16, void* stream);
+                   float drop_p, unsigned long long drop_seed, const unsigned long long* drop_epoch, int qkv_bf16, void* stream);
 /* drop_p in [0, 1) (0 = off): nn.Dropout on the attention probabilities (cswin_unet.py:101, attn_drop_rate): y = ((P o M) v) + lepe
  * with M = keep / (1 - drop_p), keep a counter-based hash of (drop_seed, batch, head, window, query, key).  cswin_attn_bwd called
- * with the same (drop_p, drop_seed) regenerates the mask; the softmax statistics (lse) are those of the undropped P. */
+ * with the same (drop_p, drop_seed) regenerates the mask; the softmax statistics (lse) are those of the undropped P.
+ * drop_epoch: NULL, or a DEVICE counter whose value is added to drop_seed when the kernel runs: a captured hipGraph (seed frozen
+ * at capture) then draws a new mask on every replay if a kernel in the graph advances the counter once per step. */
 size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* heads, const int* idx, int split);
 /* autograd backward of the above: dqkv (B, L, 3C), dlepe_w[i] (Cb, 9), dlepe_b[i] (Cb) are overwritten.
  * y0 = the forward's y0 output (NOT y).  The per-window partial slabs of the LePE conv weight / bias gradient are reduced by
@@ -86,8 +88,8 @@ size_t cswin_attn_bwd_workspace(int B, int reso, int C, int nbranch, const int* 
 int cswin_attn_bwd(const float* qkv, const float* const* lepe_w, const float* const* lepe_b, const float* lse,
                    const float* y0, const float* dy, float* dqkv, float* const* dlepe_w, float* const* dlepe_b,
                    void* workspace, size_t ws_bytes, int B, int reso, int C, int nbranch, const int* heads, const int* idx,
-                   int split, float scale, cswin_reduce_job* deferred, float drop_p, unsigned long long drop_seed, int qkv_bf16,
-                   void* stream);
+                   int split, float scale, cswin_reduce_job* deferred, float drop_p, unsigned long long drop_seed,
+                   const unsigned long long* drop_epoch, int qkv_bf16, void* stream);
 /* qkv_bf16: storage mode of both attention entry points.  0: every tensor fp32.  1: qkv (and dqkv) are STORED as bf16 -- the
  * output format of cswin_linear_fwd(io_bf16 bit 1).  3: additionally y and y0 (the forward outputs) are stored
  * as bf16 -- the input format of the proj Linear's io_bf16 bit 0.  In modes 0 - 3 the arithmetic of the attention kernels is
@@ -230,7 +232,8 @@ int cswin_multi_copy(const void* table, int nchunks, void* stream);
  * allowed.  The random stream is this library's own: torch's Philox stream cannot be reproduced (parity unpinned, as for
  * DropPath); tests extract the mask by running the kernel on ones. */
 int cswin_dropout(const float* x, const float* residual, const float* row_scale, float* y, long n, long elems_per_sample,
-                  float p, unsigned long long seed, void* stream);
+                  float p, unsigned long long seed, const unsigned long long* seed_epoch, void* stream);
+/* seed_epoch: as drop_epoch of cswin_attn_fwd (device counter added to the seed; NULL: none). */
 /* bf16 gradient wire for the data-parallel all-reduce (replaces DataParallel's fp32 reduce_add, trainer.py:37-38):
    fp32 -> bf16 round-to-nearest-even / bf16 -> fp32 over n elements (src of pack, dst of unpack 16-B aligned) */
 int cswin_pack_bf16(const float* src, void* dst_bf16, long n, void* stream);

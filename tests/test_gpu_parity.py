@@ -1027,8 +1027,8 @@ def test_attention_bf16_y_storage_bit_exact(reso, idx, split, dim, heads):
     E = lambda *sh, dt=torch.float32: torch.empty(*sh, dtype=dt, device=DEV)
     y32, y16, lse32, lse16 = E(B, L, C), E(B, L, C, dt=torch.bfloat16), E(B, nh, L), E(B, nh, L)
     z32, z16 = E(B, L, C), E(B, L, C, dt=torch.bfloat16)          # y0 = P V, the output without the LePE term (the backward's input)
-    call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y32), ptr(z32), ptr(lse32), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, 1, stream())
-    call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y16), ptr(z16), ptr(lse16), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, 3, stream())
+    call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y32), ptr(z32), ptr(lse32), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, None, 1, stream())
+    call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y16), ptr(z16), ptr(lse16), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, None, 3, stream())
     assert bool((y16.view(torch.int16) == y32.bfloat16().view(torch.int16)).all()) and bool((lse16 == lse32).all())
     assert bool((z16.view(torch.int16) == z32.bfloat16().view(torch.int16)).all())
     nbytes = lib().cswin_attn_bwd_workspace(B, reso, C, 1, ha, ia, split)
@@ -1036,14 +1036,14 @@ def test_attention_bf16_y_storage_bit_exact(reso, idx, split, dim, heads):
     for mode, y in ((1, z16.float()), (3, z16)):
         dq, dw_, db_, ws = E(B, L, 3 * C, dt=torch.bfloat16), E(C, 9), E(C), E(nbytes // 4 + 4)
         call("cswin_attn_bwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(lse32), ptr(y), ptr(dy), ptr(dq), _ptr_array([dw_]),
-             _ptr_array([db_]), ptr(ws), nbytes, B, reso, C, 1, ha, ia, split, 0.0, None, 0.0, 0, mode, stream())
+             _ptr_array([db_]), ptr(ws), nbytes, B, reso, C, 1, ha, ia, split, 0.0, None, 0.0, 0, None, mode, stream())
         torch.cuda.synchronize()
         res.append((dq, dw_, db_))
     (a, b, c), (d, e, f) = res
     assert bool((a.view(torch.int16) == d.view(torch.int16)).all()) and bool((b == e).all()) and bool((c == f).all())
     from cswin_unet_amd._lib import CswinHipError
     with pytest.raises(CswinHipError):
-        call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y16), ptr(z16), ptr(lse16), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, 2, stream())
+        call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y16), ptr(z16), ptr(lse16), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, None, 2, stream())
 
 
 @pytest.mark.parametrize("reso,idx,split,dim,heads", [(56, 0, 1, 64, 2), (28, 1, 2, 128, 4), (14, 0, 7, 256, 8), (7, -1, 7, 512, 16),
@@ -1070,10 +1070,10 @@ def test_attention_bf16_matrix_instructions_vs_fp32(reso, idx, split, dim, heads
     res = {}
     for mode in (3, 7):
         y, z, lse = E(B, L, C, dt=torch.bfloat16), E(B, L, C, dt=torch.bfloat16), E(B, nh, L)
-        call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y), ptr(z), ptr(lse), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, mode, stream())
+        call("cswin_attn_fwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(y), ptr(z), ptr(lse), B, reso, C, 1, ha, ia, split, 0.0, 0.0, 0, None, mode, stream())
         dq, dw_, db_, ws = E(B, L, 3 * C, dt=torch.bfloat16), E(C, 9), E(C), E(nbytes // 4 + 4)
         call("cswin_attn_bwd", ptr(qkv16), _ptr_array([lw]), _ptr_array([lb]), ptr(lse), ptr(z), ptr(dy), ptr(dq), _ptr_array([dw_]),
-             _ptr_array([db_]), ptr(ws), nbytes, B, reso, C, 1, ha, ia, split, 0.0, None, 0.0, 0, mode, stream())
+             _ptr_array([db_]), ptr(ws), nbytes, B, reso, C, 1, ha, ia, split, 0.0, None, 0.0, 0, None, mode, stream())
         torch.cuda.synchronize()
         res[mode] = (y.float(), lse, dq.float(), dw_, db_)
     names, bounds = ("y", "lse", "dqkv", "dlepe_w", "dlepe_b"), (5e-3, 1e-3, 8e-3, 1e-6, 1e-6)
@@ -1405,6 +1405,27 @@ def test_graph_replay_sees_weights_written_from_outside(N, bf16_matmul):
     assert abs(l1 - l2) < 2e-4 * abs(l2), (l0, l1, l2)
 
 
+def test_live_dropout_stays_under_hipgraph_and_redraws(N):
+    """A model with live nn.Dropouts (drop_rate, attn_drop_rate > 0; cswin_unet.py:25,27,101,135) keeps its captured step: the host
+    seeds are frozen at capture, the device-resident epoch that every dropout kernel adds to its seed is advanced inside the graph.
+    With lr = 0 the weights never move, so two replays differ only through their masks: the losses must differ from step to step
+    (fresh masks), stay close to the mask-free loss (p is small), and a second engine replays a different sequence."""
+    from cswin_unet_amd.trainer import DataParallelTrainer
+    mk = lambda dr: fill_state_dict(N.CSWinTransformer(img_size=224, num_classes=9, embed_dim=64, depth=[1, 1, 1, 1], split_size=[1, 2, 7, 7],
+                                                       num_heads=[2, 4, 8, 16], qkv_bias=True, drop_rate=dr, attn_drop_rate=dr,
+                                                       drop_path_rate=0.).to(DEV)).train()
+    img = T(det_normal("livedrop.x", (2, 1, 224, 224))).repeat(1, 3, 1, 1)
+    lab = T(det_labels("livedrop.labels", (2, 224, 224), 9))
+    ref = float(DataParallelTrainer(mk(0.0), 9, base_lr=0.0, max_iterations=100, use_graph=True).train_step(img, lab)[0])
+    torch.manual_seed(7)
+    tr = DataParallelTrainer(mk(0.05), 9, base_lr=0.0, max_iterations=100, use_graph=True)
+    assert tr.engine.use_graph
+    losses = [float(tr.train_step(img, lab)[0]) for _ in range(5)]
+    assert tr.engine._graphs is not None, "the step was not captured"
+    assert len({round(v, 6) for v in losses}) == 5, losses                       # every replay drew another mask set
+    assert all(abs(v - ref) < 0.1 * abs(ref) for v in losses) and all(abs(v - ref) > 1e-6 * abs(ref) for v in losses), (ref, losses)
+
+
 def test_bf16_wire_pack_unpack():
     from cswin_unet_amd._lib import call, ptr, stream
     for n in (4096 * 4, 1000003):
@@ -1426,7 +1447,9 @@ def _dropout_factor(shape, p, seed):
     from cswin_unet_amd._lib import call, ptr, stream
     ones = torch.ones(shape, device=DEV)
     out = torch.empty_like(ones)
-    call("cswin_dropout", ptr(ones), None, None, ptr(out), ones.numel(), ones.numel() // shape[0], float(p), int(seed), stream())
+    from cswin_unet_amd.ops import dropout_epoch                   # the device-resident epoch every dropout launch of ops adds to its seed
+    call("cswin_dropout", ptr(ones), None, None, ptr(out), ones.numel(), ones.numel() // shape[0], float(p), int(seed),
+         ptr(dropout_epoch(ones.device)), stream())
     return out
 
 
@@ -1502,7 +1525,7 @@ def test_attention_probability_dropout(ops, reso, idx, split, dim, heads):
     def fwd(qkv, lw, lb, p, sd, want_y0=False):
         y, z, lse = E(B, L, C), E(B, L, C), E(B, nh, L)
         call("cswin_attn_fwd", ptr(qkv), _ptr_array([lw]), _ptr_array([lb]), ptr(y), ptr(z) if want_y0 else None, ptr(lse), B, reso, C, 1, ha, ia,
-             split, 0.0, p, sd, 0, stream())
+             split, 0.0, p, sd, None, 0, stream())
         return (y, lse, z) if want_y0 else (y, lse)
 
     # statistics
@@ -1524,7 +1547,7 @@ def test_attention_probability_dropout(ops, reso, idx, split, dim, heads):
     y, lse, z = fwd(qkv, lw, lb, p_drop, seed, want_y0=True)
     dq, dw_, db_, ws = E(B, L, 3 * C), E(C, 9), E(C), E(nbytes // 4 + 4)
     call("cswin_attn_bwd", ptr(qkv), _ptr_array([lw]), _ptr_array([lb]), ptr(lse), ptr(z), ptr(dy), ptr(dq), _ptr_array([dw_]),
-         _ptr_array([db_]), ptr(ws), nbytes, B, reso, C, 1, ha, ia, split, 0.0, None, p_drop, seed, 0, stream())
+         _ptr_array([db_]), ptr(ws), nbytes, B, reso, C, 1, ha, ia, split, 0.0, None, p_drop, seed, None, 0, stream())
     eps = 1e-2
     yp, _ = fwd(qkv + eps * d, lw, lb, p_drop, seed)
     ym, _ = fwd(qkv - eps * d, lw, lb, p_drop, seed)

@@ -18,7 +18,7 @@ ia, ha = (ctypes.c_int * nb)(*idx), (ctypes.c_int * nb)(*hb)
 pa = lambda ts: (ctypes.c_void_p * nb)(*[t.data_ptr() for t in ts])
 nbytes = lib().cswin_attn_bwd_workspace(batch, reso, C, nb, ha, ia, split[si]); ws = torch.empty(nbytes // 4 + 4, device=dev)
 for _ in range(reps):
-    call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(y0), ptr(lse), batch, reso, C, nb, ha, ia, split[si], 0.0, 0.0, 0, 0, stream())
-    call("cswin_attn_bwd", ptr(qkv), pa(w), pa(b), ptr(lse), ptr(y0), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws), nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, None, 0.0, 0, 0, stream())
+    call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(y0), ptr(lse), batch, reso, C, nb, ha, ia, split[si], 0.0, 0.0, 0, None, 0, stream())
+    call("cswin_attn_bwd", ptr(qkv), pa(w), pa(b), ptr(lse), ptr(y0), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws), nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, None, 0.0, 0, None, 0, stream())
 torch.cuda.synchronize()
 print("algorithmic MB: fwd", 16 * L * C * batch / 1e6, "bwd", 28 * L * C * batch / 1e6)

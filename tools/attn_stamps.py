@@ -17,13 +17,13 @@ dqkv = torch.empty_like(qkv); dw = [torch.empty_like(t) for t in w]; db = [torch
 ia, ha = (ctypes.c_int * nb)(*idx), (ctypes.c_int * nb)(*hb)
 pa = lambda ts: (ctypes.c_void_p * nb)(*[t.data_ptr() for t in ts])
 nbytes = lib().cswin_attn_bwd_workspace(batch, reso, C, nb, ha, ia, split[si]); ws = torch.empty(nbytes // 4 + 4, device=dev)
-call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(y0), ptr(lse), batch, reso, C, nb, ha, ia, split[si], 0.0, 0.0, 0, 0, stream())
-def bwd(): call("cswin_attn_bwd", ptr(qkv), pa(w), pa(b), ptr(lse), ptr(y0), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws), nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, None, 0.0, 0, 0, stream())
+call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(y0), ptr(lse), batch, reso, C, nb, ha, ia, split[si], 0.0, 0.0, 0, None, 0, stream())
+def bwd(): call("cswin_attn_bwd", ptr(qkv), pa(w), pa(b), ptr(lse), ptr(y0), ptr(dy), ptr(dqkv), pa(dw), pa(db), ptr(ws), nbytes, batch, reso, C, nb, ha, ia, split[si], 0.0, None, 0.0, 0, None, 0, stream())
 for _ in range(3): bwd()
 torch.cuda.synchronize()
 st = torch.zeros(1 << 16, 8, dtype=torch.int64, device=dev)
 h = lib(); h.cswin_debug_set_attn_stamps.argtypes = [ctypes.c_void_p]
-def fwd(): call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(y0), ptr(lse), batch, reso, C, nb, ha, ia, split[si], 0.0, 0.0, 0, 0, stream())
+def fwd(): call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(y0), ptr(lse), batch, reso, C, nb, ha, ia, split[si], 0.0, 0.0, 0, None, 0, stream())
 h.cswin_debug_set_attn_stamps(ctypes.c_void_p(st.data_ptr())); (fwd if FWD else bwd)(); torch.cuda.synchronize(); h.cswin_debug_set_attn_stamps(None)
 s = st.cpu().numpy(); s = s[s[:, 0] != 0]
 print(f"stage {si+1}: {len(s)} workgroups")
