@@ -699,13 +699,14 @@ __device__ __forceinline__ float row16_sum(float v) {
 // Fused backward, windows of up to 112 tokens: one workgroup per (branch, window, head) unit.
 // LDS: QK [NP][LDT] (Q, later K) | Ds [NP][LDT] (dO) | VS (V, later the dS image [N][ds_stride] + pad) | lse, delta [NP] |
 // LePE taps + bias [10][HD]: 73 KB for N = 98, two workgroups per CU.  Wave w owns the 16 keys of key tile w.  Per item:
-//   A  q, v, dO, y0, lse, taps: global -> registers -> LDS; delta[q] = sum_d dO[q][d] y0[q][d] (= rowsum(P o dP): y0 = P V is the forward's
+//   A  q, lse -> LDS and the S tiles of every query tile (MFMA) while the other loads are in flight; then v, dO, y0, taps ->
+//      LDS; delta[q] = sum_d dO[q][d] y0[q][d] (= rowsum(P o dP): y0 = P V is the forward's
 //      output WITHOUT the LePE term, saved by the forward for exactly this) from the registers being staged, an 8-lane DPP sum
 //      per token; K / V fragments of the wave's keys -> registers; barrier
 //   B  LePE conv weight / bias gradient: wave w takes taps w, w + NT, ...; a lane = (token slice, 16-B channel chunk), the eight
 //      slices meet by DPP / shuffles, lanes 0-7 store the (window, head) partial -- no LDS scratch, no barrier
-//   C  barrier (V image dead); per query tile: S, dP (MFMA) -> P, dS (VALU) -> dV^T += dO^T P, dK^T += Q^T dS (MFMA, the P / dS
-//      accumulator tiles are the B operands as they stand); dS -> LDS over the V image.  The S / dP products of tile qt + 1 are
+//   C  barrier (V image dead); per query tile: dP (MFMA) -> P, dS (VALU) -> dV^T += dO^T P, dK^T += Q^T dS (MFMA, the P / dS
+//      accumulator tiles are the B operands as they stand); dS -> LDS over the V image.  The dP product of tile qt + 1 is
 //      issued before the VALU work of tile qt.  Then dV += LePE^T(dO); dK, dV -> global
 //   D  barrier; K fragments -> LDS over the dead Q image; barrier; dQ^T = K^T dS^T per query tile (one per wave) -> global
 template <int NT, int ST>
@@ -747,24 +748,21 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd3_kernel(AttnParams p) {
         const float* qkv_b = p.qkv + (long)w.b * L * C3;
         const float* dy_b = p.dy + (long)w.b * L * p.C;
         const float* y_b = p.y_in + (long)w.b * L * p.C;
+        // loads in the order of their use: q rows, this wave's K fragments and lse feed the S products, which run while the rest
+        // (dO, y0, v) is still on its way
+        int lrow[2];
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int idx = tid + it * T, row = idx >> 3, c4 = idx & 7;
             qv[it] = {};
-            vv[it] = {};
-            yv[it] = {};
-            dv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
             bbits[it] = 0;
+            lrow[it] = -1;
             if (row < N) {
                 const int r = br.W_sp > 1 ? fdiv(row, br.m_Wsp) : row, c = row - r * br.W_sp;
                 bbits[it] = (r >= 1 ? 1 : 0) | (r <= br.H_sp - 2 ? 2 : 0) | (c >= 1 ? 4 : 0) | (c <= br.W_sp - 2 ? 8 : 0) | 16;
                 if (4 * c4 < p.hd) {
-                    const int l = (w.ih * br.H_sp + r) * p.reso + w.iw * br.W_sp + c;
-                    const float* src = qkv_b + (long)l * C3 + ch0 + 4 * c4;
-                    qv[it] = ldq_raw<Q16>(p, src);
-                    vv[it] = ldq_raw<Q16>(p, src + 2 * p.C);
-                    dv[it] = *reinterpret_cast<const f32x4*>(dy_b + (long)l * p.C + ch0 + 4 * c4);
-                    yv[it] = ldy_raw<Y16>(p, y_b + (long)l * p.C + ch0 + 4 * c4);
+                    lrow[it] = (w.ih * br.H_sp + r) * p.reso + w.iw * br.W_sp + c;
+                    qv[it] = ldq_raw<Q16>(p, qkv_b + (long)lrow[it] * C3 + ch0 + 4 * c4);
                 }
             }
         }
@@ -778,6 +776,18 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd3_kernel(AttnParams p) {
         }
         lsev = INFINITY;                                     // +inf -> P = 0 on padded query rows
         if (tid < N) lsev = p.lse[((long)w.b * p.heads_total + br.head0 + w.g) * L + token_of(br, w, p.reso, tid)];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int c4 = (tid + it * T) & 7;
+            vv[it] = {};
+            yv[it] = {};
+            dv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (lrow[it] >= 0) {
+                dv[it] = *reinterpret_cast<const f32x4*>(dy_b + (long)lrow[it] * p.C + ch0 + 4 * c4);
+                yv[it] = ldy_raw<Y16>(p, y_b + (long)lrow[it] * p.C + ch0 + 4 * c4);
+                vv[it] = ldq_raw<Q16>(p, qkv_b + (long)lrow[it] * C3 + ch0 + 4 * c4 + 2 * p.C);
+            }
+        }
         {
             const int tap = tid / HD, ch = tid - tap * HD, cb = ch0 - br.c0 + ch;
             wl0 = (tid >= 10 * HD || ch >= p.hd) ? 0.f : (tap < 9 ? br.lepe_w[cb * 9 + tap] : br.lepe_b[cb]);
@@ -799,11 +809,48 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd3_kernel(AttnParams p) {
         const bool kvalid = tk < N;
         const int lk = kvalid ? token_of(br, w, p.reso, tk) : 0;
 
-        // ---- A: registers -> LDS; delta ----
+        // ---- A1: Q image, lse, K fragments ----
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int idx = tid + it * T, row = idx >> 3, c4 = idx & 7;
             *reinterpret_cast<f32x4*>(&QK[row * LDT + 4 * c4]) = qcv(qv[it]);
+        }
+        if (tid < NP) lse_s[tid] = lsev;
+        float kf[8], vf[8];
+        {
+            const f32x4 k0 = qcv(k0r), k1 = qcv(k1r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                kf[e] = k0[e];
+                kf[4 + e] = k1[e];
+            }
+        }
+        lds_barrier();
+        ATTN_STAMP(1);
+        // ---- S tiles of all query tiles x this wave's keys (MFMA): they need q and k only, and run in the shadow of the dO / y0 /
+        // v loads (at kernel start every workgroup of the launch waits for its loads at the same time: nothing else hides them)
+        const attn_bf16x8 kb = pk8(f32x4{kf[0], kf[1], kf[2], kf[3]}, f32x4{kf[4], kf[5], kf[6], kf[7]});       // M16 only
+        f32x4 Sq[NT];
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+            const float* qp = &QK[(16 * qt + li) * LDT + 8 * kq];
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(qp), q1 = *reinterpret_cast<const f32x4*>(qp + 4);
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (M16) {
+                sa = mfma32(pk8(q0, q1), kb, sa);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sa = mfma4(q0[e], kf[e], sa);          // S[q][key] = sum_d Q[q][d] K[key][d]
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sa = mfma4(q1[e], kf[4 + e], sa);
+            }
+            Sq[qt] = sa;
+        }
+
+        // ---- A2: dO, V images; delta; border bits; zero row; LePE taps; bias gradient ----
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + it * T, row = idx >> 3, c4 = idx & 7;
             *reinterpret_cast<f32x4*>(&VS[row * LDT + 4 * c4]) = qcv(vv[it]);
             *reinterpret_cast<f32x4*>(&Ds[row * LDT + 4 * c4]) = dv[it];
             const f32x4 y4 = qcv(yv[it]);
@@ -813,6 +860,7 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd3_kernel(AttnParams p) {
                 reinterpret_cast<int*>(Ds)[row * LDT + HD] = bbits[it];
             }
         }
+        if (tid < 8) *reinterpret_cast<f32x4*>(&VS[NP * LDT + 4 * tid]) = f32x4{0.f, 0.f, 0.f, 0.f};      // the zero row behind the V image
         {
             // LePE bias gradient = sum of dO over the window's tokens: this thread's two rows share its channel chunk (lane & 7); the
             // wave's eight row groups meet by DPP / swaps, the waves in the [NT][HD] patch behind the taps (summed when stored)
@@ -825,21 +873,10 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd3_kernel(AttnParams p) {
             }
             if (lane < 8) *reinterpret_cast<f32x4*>(&Gl[(9 + wave) * HD + 4 * lane]) = bs;
         }
-        if (tid < 8) *reinterpret_cast<f32x4*>(&VS[NP * LDT + 4 * tid]) = f32x4{0.f, 0.f, 0.f, 0.f};      // the zero row behind the V image
-        if (tid < NP) lse_s[tid] = lsev;
         if (tid < 10 * HD) Wl[tid] = wl0;
         if (tid + T < 10 * HD) Wl[tid + T] = wl1;
-        float kf[8], vf[8];
-        {
-            const f32x4 k0 = qcv(k0r), k1 = qcv(k1r);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                kf[e] = k0[e];
-                kf[4 + e] = k1[e];
-            }
-        }
         lds_barrier();
-        ATTN_STAMP(1);
+        ATTN_STAMP(2);
         {
             const float* vp = &VS[tk * LDT + 8 * kq];
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp), v1 = *reinterpret_cast<const f32x4*>(vp + 4);
@@ -850,7 +887,6 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd3_kernel(AttnParams p) {
             }
         }
 
-        ATTN_STAMP(2);
         // ---- B: LePE conv weight gradient of this (window, head): dW[tap][ch] = sum_t dO[t][ch] V[nbr(t, tap)][ch] ----
         // The live taps (all nine, or the three along a one-token-wide stripe) are dealt to the waves round robin.  A lane =
         // (token 8 i + j, 16-B channel chunk c4), j = lane >> 3: per step i the wave covers eight consecutive image rows, so every
@@ -961,41 +997,32 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd3_kernel(AttnParams p) {
         f32x4 dVt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         f32x4 dKt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         const bool colok = 16 * kw + li < S;               // dS columns beyond the stride would land in the next row
-        const attn_bf16x8 kb = pk8(f32x4{kf[0], kf[1], kf[2], kf[3]}, f32x4{kf[4], kf[5], kf[6], kf[7]});       // M16 only
-        const attn_bf16x8 vb = pk8(f32x4{vf[0], vf[1], vf[2], vf[3]}, f32x4{vf[4], vf[5], vf[6], vf[7]});
-        auto s_dp = [&](int qt, f32x4& sa, f32x4& da) {
-            const float* qp = &QK[(16 * qt + li) * LDT + 8 * kq];
+        const attn_bf16x8 vb = pk8(f32x4{vf[0], vf[1], vf[2], vf[3]}, f32x4{vf[4], vf[5], vf[6], vf[7]});       // M16 only
+        auto dp_tile = [&](int qt, f32x4& da) {
             const float* dp = &Ds[(16 * qt + li) * LDT + 8 * kq];
-            const f32x4 q0 = *reinterpret_cast<const f32x4*>(qp), q1 = *reinterpret_cast<const f32x4*>(qp + 4);
             const f32x4 d0 = *reinterpret_cast<const f32x4*>(dp), d1 = *reinterpret_cast<const f32x4*>(dp + 4);
-            sa = da = f32x4{0.f, 0.f, 0.f, 0.f};
+            da = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (M16) {
-                sa = mfma32(pk8(q0, q1), kb, sa);
                 da = mfma32(pk8(d0, d1), vb, da);
                 return;
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sa = mfma4(q0[e], kf[e], sa);               // S[q][key] = sum_d Q[q][d] K[key][d]
-                da = mfma4(d0[e], vf[e], da);               // dP[q][key] = sum_d dO[q][d] V[key][d]
-            }
+            for (int e = 0; e < 4; ++e) da = mfma4(d0[e], vf[e], da);               // dP[q][key] = sum_d dO[q][d] V[key][d]
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sa = mfma4(q1[e], kf[4 + e], sa);
-                da = mfma4(d1[e], vf[4 + e], da);
-            }
+            for (int e = 0; e < 4; ++e) da = mfma4(d1[e], vf[4 + e], da);
         };
         unsigned keep = ~0u;                                // attention dropout only: bit 4 qt + r = keep (query 16 qt + 4 kq + r, key tk)
         if (p.drop_p > 0.f)
             keep = attn_keep_bits<4 * NT>(p, attn_unit_id(p, br, w.b, w.g, w.win), N,
                                           [&](int i, int& q_, int& k_) { q_ = 16 * (i >> 2) + 4 * kq + (i & 3); k_ = tk; });
         {
-            f32x4 sa, da;
-            s_dp(0, sa, da);
+            f32x4 da;
+            dp_tile(0, da);
 #pragma unroll
             for (int qt = 0; qt < NT; ++qt) {
-                f32x4 sn = sa, dn = da;
-                if (qt + 1 < NT) s_dp(qt + 1, sn, dn);
+                f32x4 dn = da;
+                if (qt + 1 < NT) dp_tile(qt + 1, dn);
+                const f32x4 sa = Sq[qt];
                 const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_s[16 * qt + 4 * kq]);
                 const f32x4 de = *reinterpret_cast<const f32x4*>(&del_s[16 * qt + 4 * kq]);
                 f32x4 pr, ds;
@@ -1035,7 +1062,6 @@ __global__ __launch_bounds__(64 * NT, 4) void attn_bwd3_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (colok && q0row + r < N) VS[(q0row + r) * S + 16 * kw + li] = ds[r];
-                sa = sn;
                 da = dn;
             }
         }

@@ -32,7 +32,7 @@ if OLD:
     names = ["P0 load -> LDS", "P1 delta + LePE wgrad", "P2 fused loop + dK/dV", "barrier + K image", "P3 dQ", "slab store"]
     if FWD: names = ["K/V -> LDS", "S + softmax (tile 0)", "PV (tile 0)", "LePE + store (+ more tiles)"]
 else:       # persistent kernels: phases of a workgroup's FIRST item, then its whole life (slot 7)
-    names = ["A stage + delta, barrier", "issue next, V fragments", "B LePE wgrad", "barrier, C fused loop, dK/dV", "barrier, K image, barrier", "D dQ"]
+    names = ["A1 q / lse -> LDS, barrier", "S tiles; A2 dO / V / delta -> LDS, barrier", "B LePE wgrad", "barrier, C fused loop, dK/dV", "barrier, K image, barrier", "D dQ"]
     if FWD: names = ["K -> LDS, barrier", "S + softmax", "V -> LDS, barrier, PV", "LePE + store"]
 for k, nm in enumerate(names):
     d = s[:, k + 1] - s[:, k]
