@@ -16,12 +16,15 @@
 // keys: dK^T and dV^T accumulate in registers over all query tiles (P / dS accumulator tiles
 // are again direct MFMA B operands), dS crosses LDS once for dQ, LePE^T(dO) is added to dV, and
 // the depthwise-conv weight/bias gradients are written as per-workgroup partial slabs (a standard
-// cswin_reduce_job, reduced deterministically by rows_sum).  Two variants by window size:
-//   attn_bwd2_kernel  N <= 112: Q/K aliased, V/dS aliased (36 KB at N = 56, 79 KB at N = 98: four / two workgroups per CU);
-//                               delta from the saved forward output, one fused S/dP/dV/dK loop
+// cswin_reduce_job, reduced deterministically by rows_sum).  delta = rowsum(dO o y0) with y0 = P V, which
+// the forward saves beside y.  Two variants by window size:
+//   attn_bwd3_kernel  N <= 112: one workgroup per unit; Q/K aliased, V/dS aliased (37 KB at N = 56, 80 KB at N = 98: four / two
+//                               workgroups per CU); S tiles formed while the dO / y0 / v loads are in flight; reduction-free LePE
+//                               weight gradient; one fused dP / dV / dK loop
 //   attn_delta / attn_bwd_kv / attn_bwd_q / lepe_wgrad   N > 112: two passes, 64 x 64 at a time
-// (An earlier single-kernel variant with separate Q, K, V, dO images and delta = rowsum(P o dP) through LDS atomics was
-// within 2 % of attn_bwd2_kernel on windows of up to 64 tokens and was dropped.)
+// Forward: attn_fwd3_kernel (N <= 128; optional query split over two workgroups), attn_fwd_kernel for larger windows.
+// (Persistent workgroups with cross-unit register prefetch were built and measured in round 3: 7-8 % slower at stages 1-2, equal at
+// stages 3-4; the non-matrix phases need the resident waves that the prefetch registers cost -- profiles/round3_notes.md.)
 // Head dims 8 / 16 / 24 / 32 share the kernels (tiles zero-padded to HD = 32).
 #include "common.h"
 #include <stdlib.h>

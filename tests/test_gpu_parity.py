@@ -1319,6 +1319,44 @@ def test_use_chk_with_drop_path_matches_plain_backward(N, ops):
         assert torch.allclose(grads[0][n], grads[1][n], rtol=1e-5, atol=1e-7), n
 
 
+def test_engine_backward_places_the_gradients_autograd_would_accumulate(N, ops):
+    """ops.engine_backward (the context HipEngine wraps around each backward phase): slab reductions are queued and run in a few
+    batched launches, and gradients of leaf parameters are written straight into the optimiser's flat gradient buffer.  The flat
+    buffer must end up holding what a plain loss.backward() leaves in .grad, also for composed weights (fused head matrix, summed stem
+    kernel: reduced immediately, copied afterwards)."""
+    from cswin_unet_amd.optim import FlatSGD
+    img = T(det_normal("eng.x", (2, 3, 224, 224)))
+    lab = T(det_labels("eng.lab", (2, 224, 224), 9))
+
+    def model():
+        net = N.CSWinTransformer(img_size=224, num_classes=9, embed_dim=64, depth=[1, 2, 2, 1], split_size=[1, 2, 7, 7],
+                                 num_heads=[2, 4, 8, 16], qkv_bias=True, drop_path_rate=0.0).to(DEV)
+        return fill_state_dict(net).train()
+
+    net = model()
+    loss, _ = ops.ce_dice_loss(net(img), lab)
+    loss.backward()
+    want = {n: p.grad.clone() for n, p in net.named_parameters()}
+
+    net = model()
+    opt = FlatSGD(net.parameters(), lr=0.0)
+    loss, _ = ops.ce_dice_loss(net(img), lab)
+    opt.zero_grad()
+    with ops.engine_backward(opt):
+        grads = torch.autograd.grad(loss, opt.params)
+    in_place = 0
+    for p, g, o in zip(opt.params, grads, opt.offsets):
+        p.grad = g
+        in_place += g.data_ptr() == opt.flat_grad.data_ptr() + 4 * o
+    assert in_place > 0.9 * len(opt.params), (in_place, len(opt.params))     # all but the composed weights
+    opt.gather_grads()
+    torch.cuda.synchronize()
+    names = [n for n, p in net.named_parameters() if p.requires_grad]
+    for n, p, o in zip(names, opt.params, opt.offsets):
+        got = opt.flat_grad[o:o + p.numel()].view(p.shape)
+        assert _rel_l2(got, want[n]) < 1e-6, (n, _rel_l2(got, want[n]))       # same slabs; the batched reduction may sum them in another order
+
+
 def test_use_chk_in_bf16_mode_matches_plain_backward(N, ops, bf16_matmul):
     """The same in the bf16 mode: the recompute runs the bf16-storage forward again, the backward finds (or does not find) the bf16
     gradient twins in another order than without checkpointing; with identical DropPath draws the gradients must agree to the

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM-side traffic of the stripe-attention kernels, one stage and one counter per rocprofv3 pass (FETCH_SIZE and WRITE_SIZE
 # cannot share a pass: MI355X_MICROARCH.md, counter slots).  Run from the repo root on the GPU box:
-#   bash tools/attn_pmc.sh && python3 tools/attn_pmc_parse.py gpurun_out/pmc profiles/round1_attn_pmc.json
+#   bash tools/attn_pmc.sh && python3 tools/attn_pmc_parse.py gpurun_out/pmc profiles/round3_attn_pmc.json
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/pmc

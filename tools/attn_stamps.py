@@ -26,19 +26,10 @@ h = lib(); h.cswin_debug_set_attn_stamps.argtypes = [ctypes.c_void_p]
 def fwd(): call("cswin_attn_fwd", ptr(qkv), pa(w), pa(b), ptr(y), ptr(y0), ptr(lse), batch, reso, C, nb, ha, ia, split[si], 0.0, 0.0, 0, None, 0, stream())
 h.cswin_debug_set_attn_stamps(ctypes.c_void_p(st.data_ptr())); (fwd if FWD else bwd)(); torch.cuda.synchronize(); h.cswin_debug_set_attn_stamps(None)
 s = st.cpu().numpy(); s = s[s[:, 0] != 0]
-print(f"stage {si+1}: {len(s)} workgroups")
-OLD = os.environ.get("CSWIN_ATTN_OLD", "0") == "1"
-if OLD:
-    names = ["P0 load -> LDS", "P1 delta + LePE wgrad", "P2 fused loop + dK/dV", "barrier + K image", "P3 dQ", "slab store"]
-    if FWD: names = ["K/V -> LDS", "S + softmax (tile 0)", "PV (tile 0)", "LePE + store (+ more tiles)"]
-else:       # persistent kernels: phases of a workgroup's FIRST item, then its whole life (slot 7)
-    names = ["A1 q / lse -> LDS, barrier", "S tiles; A2 dO / V / delta -> LDS, barrier", "B LePE wgrad", "barrier, C fused loop, dK/dV", "barrier, K image, barrier", "D dQ"]
-    if FWD: names = ["K -> LDS, barrier", "S + softmax", "V -> LDS, barrier, PV", "LePE + store"]
+print(f"stage {si+1} {'forward' if FWD else 'backward'}: {len(s)} workgroups")
+names = ["A1 q / lse -> LDS, barrier", "S tiles; A2 dO / V / delta -> LDS, barrier", "B LePE wgrad", "barrier, C fused loop, dK/dV", "barrier, K image, barrier", "D dQ"]
+if FWD: names = ["K -> LDS, barrier", "S + softmax", "V -> LDS, barrier, PV", "LePE + store"]
 for k, nm in enumerate(names):
     d = s[:, k + 1] - s[:, k]
-    print(f"  {nm:28s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f} shader cycles (s_memtime)")
-E = len(names)
-d = s[:, E] - s[:, 0]; print(f"  {'first item':28s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f}")
-if not OLD:
-    d = s[:, 7] - s[:, 0]; print(f"  {'workgroup life':28s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f} max {d.max():8.0f}")
-    d = s[:, 7] - s[:, E]; print(f"  {'after the first item':28s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f} max {d.max():8.0f}")
+    print(f"  {nm:44s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f} shader cycles (s_memtime)")
+d = s[:, len(names)] - s[:, 0]; print(f"  {'workgroup life':44s} mean {d.mean():8.0f} p90 {np.percentile(d, 90):8.0f} max {d.max():8.0f}")
