@@ -52,6 +52,39 @@ def test_library_loads_and_exports_header_symbols():
     assert isinstance(h.cswin_last_error(), bytes)
 
 
+def _integration_stub():
+    """The reference-side ctypes stub of INTEGRATION.md section B (the python block that binds cswin_attn_fwd)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = [b for b in blocks if "lib.cswin_attn_fwd.argtypes" in b]
+    assert len(stub) == 1
+    return text, stub[0]
+
+
+def test_integration_md_stub_matches_the_binding():
+    """INTEGRATION.md shows a maintainer how to bind the C ABI from the reference code base: its argtypes for cswin_attn_fwd, the
+    ABI version it asserts and the entry-point count it quotes must be those of cswin_unet_amd/_lib.py (the stub went stale once
+    when the signature grew)."""
+    from cswin_unet_amd import _lib
+    text, stub = _integration_stub()
+    line = re.search(r"lib\.cswin_attn_fwd\.argtypes = (\[.*?\])", stub).group(1)
+    P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    assert eval(line, {"P": P, "I": I, "F": F, "ctypes": ctypes}) == _lib.SIGNATURES["cswin_attn_fwd"][1]
+    assert int(re.search(r"holds all (\d+) signatures", stub).group(1)) == len(_lib.SIGNATURES)
+    assert int(re.search(r"cswin_abi_version\(\) == (\d+)", stub).group(1)) == _lib.ABI_VERSION
+    call = re.search(r"lib\.cswin_attn_fwd\((.*?)\n\s*if rc", stub, flags=re.S).group(1)
+    depth, nargs = 0, 1
+    for ch in re.sub(r"#.*", "", call):               # top-level commas of the call = arguments - 1
+        depth += ch in "([" ; depth -= ch in ")]"
+        nargs += ch == "," and depth == 0
+    assert nargs == len(_lib.SIGNATURES["cswin_attn_fwd"][1]), nargs
+    rows = [ln.split("|")[1] for ln in text.splitlines() if ln.startswith("| `cswin_")]      # first column of the entry-point table
+    assert len(rows) >= 12
+    for cell in rows:
+        for name in re.findall(r"cswin_[a-z0-9_]+", cell):           # every entry point the table names exists (prefix forms allowed)
+            assert any(k.startswith(name) for k in _lib.SIGNATURES), name
+
+
 def test_workspace_queries_are_host_only():
     from cswin_unet_amd import _lib
     h = _lib.lib()

@@ -211,6 +211,30 @@ def test_attention_vs_golden(N, golden, reso, idx, split, dim, heads):
             f.write(f"attn_golden.{key}.{name}: {err:.3e}\n")
 
 
+def test_integration_md_ctypes_stub_runs(N):
+    """The reference-side stub of INTEGRATION.md (a maintainer's own ctypes binding of cswin_attn_fwd) is executed as written and
+    must reproduce what the CSWinBlock's attention computes from the same qkv."""
+    import re as _re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    stub = [b for b in _re.findall(r"```python\n(.*?)```", text, flags=_re.S) if "lib.cswin_attn_fwd.argtypes" in b][0]
+    stub = stub.replace('"cswin_unet_amd/libcswin_hip.so"', repr(os.path.join(root, "cswin_unet_amd", "libcswin_hip.so")))
+    ns = {}
+    exec(compile(stub, "INTEGRATION.md", "exec"), ns)
+    blk = N.CSWinBlock(dim=128, reso=28, num_heads=4, split_size=2, qkv_bias=True, drop_path=0.).to(DEV)
+    fill_state_dict(blk).eval()
+    x = T(det_normal("stub.x", (2, 28 * 28, 128)))
+    with torch.no_grad():
+        qkv = blk.qkv(blk.norm1(x)).contiguous()                                   # (B, L, 3C), [q | k | v]
+        y, y0, lse = ns["lepe_attention_both_branches"](qkv, [a.get_v for a in blk.attns], 28, 2, 4)
+        q, k, v = qkv.reshape(2, -1, 3, 128).permute(2, 0, 1, 3)
+        ref = torch.cat([blk.attns[0]([q[..., :64].contiguous(), k[..., :64].contiguous(), v[..., :64].contiguous()]),
+                         blk.attns[1]([q[..., 64:].contiguous(), k[..., 64:].contiguous(), v[..., 64:].contiguous()])], dim=2)
+    torch.cuda.synchronize()
+    assert _rel_l2(y, ref) < 1e-6, _rel_l2(y, ref)
+    assert bool(torch.isfinite(y0).all()) and bool(torch.isfinite(lse).all())
+
+
 @pytest.mark.parametrize("reso,idx,split,dim,heads", ATTN384)
 def test_attention_384_fwd_bwd_vs_golden(N, golden, reso, idx, split, dim, heads):
     """384x384 stripe shapes (N = 96, 288, 144): forward with online tiles over up to 18 key tiles, backward through the
