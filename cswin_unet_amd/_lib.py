@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libcswin_hip.so")
 
 P, I, F, SZ, L, D = c_void_p, c_int, c_float, c_size_t, c_long, c_double
 
-ABI_VERSION = 3          # CSWIN_ABI_VERSION of the include/cswin_hip.h this table mirrors; lib() refuses any other library
+ABI_VERSION = 4          # CSWIN_ABI_VERSION of the include/cswin_hip.h this table mirrors; lib() refuses any other library
 
 # name -> (restype, argtypes); mirrors include/cswin_hip.h one to one (tests/test_abi.py checks both ways)
 SIGNATURES = {
@@ -35,6 +35,7 @@ SIGNATURES = {
     "cswin_linear_bwd_weight_workspace": (SZ, [I, I, I]),
     "cswin_linear_bwd_weight": (I, [P, P, P, I, P, I, P, P, P, SZ, I, I, I, P, I, P]),
     "cswin_linear_bwd_weight_batch": (I, [P, I, P, P]),
+    "cswin_linear_bwd_tail": (I, [P, P, P, I, I, I, P, I, P, P]),
     "cswin_rows_sum_multi": (I, [P, I, P]),
     "cswin_conv_tok_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "cswin_conv_tok_bwd_data": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),

@@ -14,7 +14,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // bumped whenever a prototype of include/cswin_hip.h changes (the same constant is defined there; tests compare the two)
-#define CSWIN_ABI_VERSION 3
+#define CSWIN_ABI_VERSION 4
 #define CSWIN_OK 0
 #define CSWIN_ERR_SHAPE (-1)
 #define CSWIN_ERR_ALIGN (-2)

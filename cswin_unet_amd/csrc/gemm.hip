@@ -189,8 +189,20 @@ struct TapRowsSrc {
 // [g*BK/KW, (g+1)*BK/KW) of every tile, the groups' accumulators are summed through LDS at the end).  When M*N is too
 // small to give every SIMD >= 2 independent MFMA chains (stage-3/4 shapes with long K) this doubles / quadruples the
 // resident waves per workgroup without a global split-K reduction.
+// floats of LDS one tile configuration needs (operand images, or the waves' epilogue patches if those are larger).  The kernels own
+// the buffer and hand it to gemm_body, so that a launch which mixes two configurations (gemm_block_tail_kernel) holds ONE buffer
+// of the larger size instead of two static arrays.
+template <int BM, int BN, int BK, int KW, bool A_RC, bool B_RC>
+constexpr int gemm_lds_floats() {
+    constexpr int NW = (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1);
+    constexpr int LDR = BK + 4;
+    constexpr int A_ELEMS = A_RC ? BM * LDR : BK * (BM + 4);
+    constexpr int B_ELEMS = B_RC ? BN * LDR : BK * (BN + 4);
+    return (A_ELEMS + B_ELEMS) > NW * EP_WAVE_FLOATS ? (A_ELEMS + B_ELEMS) : NW * EP_WAVE_FLOATS;
+}
+
 template <int BM, int BN, int BK, int KW, bool A_RC, bool B_RC, int VEC, int EPI, bool SCALE_A, int PREC, class ASrc, class BSrc>
-__device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Epilogue& epi, int M, int N, int R,
+__device__ __forceinline__ void gemm_body(float* lds, const ASrc& A, const BSrc& B, const Epilogue& epi, int M, int N, int R,
                                           int r_per_split, int tiles_m, int tiles_n, int bid, int nblk, int stamp_row) {
     // waves of one k-group: 2 x 2 for 64 x 64 (and larger) tiles, 2 x 1 for 64 x 32: the narrow tile
     // exists for launches whose 64 x 64 tile count is a poor multiple of the 256 CUs (every workgroup is resident at once,
@@ -203,8 +215,8 @@ __device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Ep
     constexpr int LDB = B_RC ? LDR : BN + 4;
     constexpr int A_ELEMS = A_RC ? BM * LDR : BK * (BM + 4);
     constexpr int B_ELEMS = B_RC ? BN * LDR : BK * (BN + 4);
-    constexpr int LDS_FLOATS = (A_ELEMS + B_ELEMS) > NW * EP_WAVE_FLOATS ? (A_ELEMS + B_ELEMS) : NW * EP_WAVE_FLOATS;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    constexpr int LDS_FLOATS = gemm_lds_floats<BM, BN, BK, KW, A_RC, B_RC>();
+    static_assert(LDS_FLOATS >= A_ELEMS + B_ELEMS && LDS_FLOATS >= NW * EP_WAVE_FLOATS, "gemm_lds_floats out of step with the tile geometry");
     float* As = lds;
     float* Bs = lds + A_ELEMS;
     // PREC == 1: both operands as [row][r] bf16 images (r-contiguous: one ds_read_b128 = the 8 k-values of a lane)
@@ -538,7 +550,8 @@ __device__ __forceinline__ void gemm_body(const ASrc& A, const BSrc& B, const Ep
 template <int BM, int BN, int BK, int KW, bool A_RC, bool B_RC, int VEC, int EPI, bool SCALE_A, int PREC, class ASrc, class BSrc>
 __global__ __launch_bounds__(64 * (BM >= 64 ? 2 : 1) * (BN >= 64 ? 2 : 1) * KW) void gemm_kernel(ASrc A, BSrc B, Epilogue epi, int M, int N, int R,
                                                     int r_per_split, int tiles_m, int tiles_n) {
-    gemm_body<BM, BN, BK, KW, A_RC, B_RC, VEC, EPI, SCALE_A, PREC, ASrc, BSrc>(A, B, epi, M, N, R, r_per_split, tiles_m, tiles_n,
+    __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BM, BN, BK, KW, A_RC, B_RC>()];
+    gemm_body<BM, BN, BK, KW, A_RC, B_RC, VEC, EPI, SCALE_A, PREC, ASrc, BSrc>(lds, A, B, epi, M, N, R, r_per_split, tiles_m, tiles_n,
                                                                               (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.x);
 }
 
@@ -561,8 +574,38 @@ template <int PREC>
 __global__ __launch_bounds__(512) void gemm_wgrad_batch_kernel(WgradBatch b) {
     int p = 0;
     while (p + 1 < b.n && (int)blockIdx.x >= b.first[p + 1]) ++p;
+    __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<64, 64, 64, 2, false, false>()];
     gemm_body<64, 64, 64, 2, false, false, 4, EPI_PLAIN, true, PREC, PlainSrc, PlainSrc>(
-        b.A[p], b.B[p], b.e[p], b.M[p], b.N[p], b.R[p], b.rps[p], b.tm[p], b.tn[p], (int)blockIdx.x - b.first[p],
+        lds, b.A[p], b.B[p], b.e[p], b.M[p], b.N[p], b.R[p], b.rps[p], b.tm[p], b.tn[p], (int)blockIdx.x - b.first[p],
+        b.first[p + 1] - b.first[p], (int)blockIdx.x);
+}
+
+// The tail of a CSWinBlock's backward in ONE launch: the data gradient of the qkv Linear (dqkv . Wqkv, the last Linear whose input
+// gradient is still missing) beside the block's four weight gradients.  Both only wait for dqkv, neither depends on the other, and
+// alone the data gradient keeps the matrix pipe busy a third of the time (profiles/round3_sq_counters_fp32.txt: 0.34 against the
+// batch's 0.50): in one launch its tiles' load waits, prologues and epilogues sit beside the weight gradients' long k-loops.
+// Workgroups [0, nd) are the data gradient's 64 x 64 tiles (two k-groups of four waves, as the weight-gradient workgroups).
+struct BlockTail {
+    PlainSrc dA, dB;
+    Epilogue de;
+    int dM, dN, dR, drps, dtm, dtn, nd;
+    WgradBatch w;
+};
+__global__ __launch_bounds__(512) void gemm_block_tail_kernel(BlockTail t) {
+    constexpr int L0 = gemm_lds_floats<64, 64, 64, 2, true, false>(), L1 = gemm_lds_floats<64, 64, 64, 2, false, false>();
+    __shared__ __attribute__((aligned(16))) float lds[L0 > L1 ? L0 : L1];
+    const WgradBatch& b = t.w;
+    const int nw = b.first[b.n];
+    if ((int)blockIdx.x >= nw) {           // the data gradient's tiles come LAST: they fill the weight gradients' tail
+        gemm_body<64, 64, 64, 2, true, false, 4, EPI_PLAIN, false, 0, PlainSrc, PlainSrc>(
+            lds, t.dA, t.dB, t.de, t.dM, t.dN, t.dR, t.drps, t.dtm, t.dtn, (int)blockIdx.x - nw, t.nd, (int)blockIdx.x);
+        return;
+    }
+    const int bid = (int)blockIdx.x;
+    int p = 0;
+    while (p + 1 < b.n && bid >= b.first[p + 1]) ++p;
+    gemm_body<64, 64, 64, 2, false, false, 4, EPI_PLAIN, true, 0, PlainSrc, PlainSrc>(
+        lds, b.A[p], b.B[p], b.e[p], b.M[p], b.N[p], b.R[p], b.rps[p], b.tm[p], b.tn[p], bid - b.first[p],
         b.first[p + 1] - b.first[p], (int)blockIdx.x);
 }
 
@@ -572,8 +615,9 @@ template <int KW, int PREC>
 __global__ __launch_bounds__(256 * KW) void gemm_conv_s2_dgrad_batch_kernel(GemmBatch<ConvTS2Src, TapRowsSrc> b) {
     int p = 0;
     while (p + 1 < b.n && (int)blockIdx.x >= b.first[p + 1]) ++p;
+    __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<64, 64, (KW == 1 ? 32 : 64), KW, true, false>()];
     gemm_body<64, 64, (KW == 1 ? 32 : 64), KW, true, false, 4, EPI_PLAIN, false, PREC, ConvTS2Src, TapRowsSrc>(
-        b.A[p], b.B[p], b.e[p], b.M[p], b.N[p], b.R[p], b.rps[p], b.tm[p], b.tn[p], (int)blockIdx.x - b.first[p],
+        lds, b.A[p], b.B[p], b.e[p], b.M[p], b.N[p], b.R[p], b.rps[p], b.tm[p], b.tn[p], (int)blockIdx.x - b.first[p],
         b.first[p + 1] - b.first[p], (int)blockIdx.x);
 }
 
@@ -790,6 +834,13 @@ size_t cswin_linear_bwd_weight_workspace(int M, int N, int K) {
 }
 
 int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferred, void* stream);
+}  // extern "C"
+namespace {
+// a plain fp32 data gradient dx[M,K] = dy[M,N] @ w[N,K] that may ride in the weight-gradient batch's launch (cswin_linear_bwd_tail)
+struct DgradRider { const float* dy; const float* w; float* dx; int M, N, K; };
+int wgrad_batch_impl(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferred, const DgradRider* rider, void* stream);
+}  // namespace
+extern "C" {
 
 // dw[N,K] = (row_scale . dy)^T @ [x | x2];  dbias[N] = colsum(row_scale . dy)
 int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, int k_split, const float* row_scale,
@@ -850,6 +901,22 @@ int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, in
 // i's slab reduction (run them with cswin_rows_sum_multi).  Falls back to separate launches when a problem is not 16-B
 // aligned / a multiple of 4 in N and K.
 int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferred, void* stream) {
+    return wgrad_batch_impl(d, n, deferred, nullptr, stream);
+}
+
+// The tail of a CSWinBlock's backward: dx[M,K] = dy[M,N] @ w[N,K] (the qkv Linear's data gradient, plain fp32, no epilogue extras)
+// and the block's weight gradients as cswin_linear_bwd_weight_batch takes them.  In fp32 with aligned operands both run in ONE
+// launch (gemm_block_tail_kernel); otherwise the data gradient is launched first and the batch follows -- same results either way.
+int cswin_linear_bwd_tail(const float* dy, const float* w, float* dx, int M, int N, int K, const cswin_wgrad_desc* d, int n,
+                          cswin_reduce_job* deferred, void* stream) {
+    CSWIN_REQUIRE(dy && w && dx && M > 0 && N > 0 && K > 0, CSWIN_ERR_SHAPE, "linear_bwd_tail: bad data-gradient arguments");
+    DgradRider r = {dy, w, dx, M, N, K};
+    return wgrad_batch_impl(d, n, deferred, &r, stream);
+}
+
+}  // extern "C"
+namespace {
+int wgrad_batch_impl(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferred, const DgradRider* rider, void* stream) {
     CSWIN_REQUIRE(d && deferred && n >= 1 && n <= WGRAD_BATCH, CSWIN_ERR_SHAPE, "linear_bwd_weight_batch: 1..%d problems and their deferred slots", WGRAD_BATCH);
     bool fast = true;
     const int precision = d[0].precision;
@@ -862,6 +929,13 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
         size_t need = cswin_linear_bwd_weight_workspace(d[i].M, d[i].N, d[i].K);
         CSWIN_REQUIRE(d[i].workspace && d[i].ws_bytes >= need, CSWIN_ERR_WORKSPACE, "linear_bwd_weight_batch: workspace %zu < %zu", d[i].ws_bytes, need);
         fast = fast && d[i].N % 4 == 0 && d[i].K % 4 == 0 && aligned16(d[i].dy) && aligned16(d[i].x) && aligned16(d[i].workspace);
+    }
+    const bool ride = rider && fast && precision == 0 && rider->N % 4 == 0 && rider->K % 4 == 0 && aligned16(rider->dy) &&
+                      aligned16(rider->w) && aligned16(rider->dx) && cswin_tuning().gemm_tail_merge;
+    if (rider && !ride) {                   // the data gradient as a launch of its own, then the batch as usual
+        int rc = cswin_linear_bwd_data(rider->dy, rider->w, rider->dx, nullptr, 0, nullptr, nullptr, 1, nullptr, rider->M, rider->N,
+                                       rider->K, precision == 1 ? 1 : 0, 0, stream);
+        if (rc) return rc;
     }
     if (!fast) {
         for (int i = 0; i < n; ++i) CSWIN_REQUIRE(d[i].io_bf16 == 0, CSWIN_ERR_ALIGN, "linear_bwd_weight_batch: bf16 storage needs N, K multiples of 4 and 16-B alignment");
@@ -943,11 +1017,29 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
     }
     b.first[n] = blocks;
     b.n = n;
-    if (precision == 1) hipLaunchKernelGGL(gemm_wgrad_batch_kernel<1>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, b);
-    else hipLaunchKernelGGL(gemm_wgrad_batch_kernel<0>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, b);
+    if (ride) {
+        BlockTail t = {};
+        Epilogue e = plain_epilogue(rider->dx, rider->K);
+        e.vec_store = epilogue_vec_ok(e, rider->K);
+        t.dA = PlainSrc{rider->dy, rider->N, rider->M, rider->N, nullptr, 1, 0};
+        t.dB = PlainSrc{rider->w, rider->K, rider->N, rider->K, nullptr, 1, 0};      // S(i = n (reduction), j = k)
+        t.de = e;
+        t.dM = rider->M; t.dN = rider->K; t.dR = rider->N; t.drps = cdiv(rider->N, BKMAX) * BKMAX;
+        t.dtm = cdiv(rider->M, 64); t.dtn = cdiv(rider->K, 64);
+        t.nd = t.dtm * t.dtn;
+        t.w = b;
+        static_assert(sizeof(BlockTail) <= 4096, "kernel argument block");
+        hipLaunchKernelGGL(gemm_block_tail_kernel, dim3(t.nd + blocks), dim3(512), 0, (hipStream_t)stream, t);
+    } else if (precision == 1) {
+        hipLaunchKernelGGL(gemm_wgrad_batch_kernel<1>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, b);
+    } else {
+        hipLaunchKernelGGL(gemm_wgrad_batch_kernel<0>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, b);
+    }
     CSWIN_LAUNCH_CHECK();
     return CSWIN_OK;
 }
+}  // namespace
+extern "C" {
 
 // -------- convolutions on the (B, H*W, C) token layout (NHWC), implicit GEMM -----------------------------------
 // w_perm: [Cout][ks*ks][Cin]  (made by cswin_conv_weight_permute from the nn.Conv2d [Cout][Cin][ks][ks] parameter)

@@ -8,7 +8,7 @@
 
 struct CswinTuning {
     // tiled GEMM family (gemm.hip)
-    int gemm_tile, gemm_kw, gemm_pad_lds, gemm_split_wgs, gemm_batch_wgs, gemm_batch_even;
+    int gemm_tile, gemm_kw, gemm_pad_lds, gemm_split_wgs, gemm_batch_wgs, gemm_batch_even, gemm_tail_merge;
     double gemm_pen2;
     // bf16 mode
     int wgrad16_on, w16_wgs, w16_even, w16_dma;             // wgrad16.hip
@@ -27,6 +27,7 @@ inline const CswinTuning& cswin_tuning() {
         c.gemm_split_wgs = geti("CSWIN_GEMM_SPLIT_WGS", 768);    // workgroup target of a stand-alone weight-gradient split
         c.gemm_batch_wgs = geti("CSWIN_GEMM_BATCH_WGS", 0);      // per-problem target of the batched weight gradient (0 = 1024 / n)
         c.gemm_batch_even = geti("CSWIN_GEMM_BATCH_EVEN", 1);    // 0 = shares in proportion to the work (slower in fp32)
+        c.gemm_tail_merge = geti("CSWIN_GEMM_TAIL_MERGE", 1);    // 0 = qkv data gradient and the weight-gradient batch as two launches
         c.gemm_pen2 = getenv("CSWIN_GEMM_PEN2") ? atof(getenv("CSWIN_GEMM_PEN2")) : 1.20;     // per-flop penalty of the 64x32 tile
         c.wgrad16_on = geti("CSWIN_WGRAD16", 1);                 // 0 = tiled family for bf16 weight gradients
         c.w16_wgs = geti("CSWIN_W16_WGS", 768);

@@ -650,11 +650,16 @@ class _CSWinBlock(Function):
         dbqkv = _grad_at(pbqkv, (3 * C,), dev) if has_qkv_bias else None
         defer_wgrad(3, dqkv, h1, None, dwqkv, dbqkv, 4, 3 * C, C, io=3)  # dy = dqkv and x = h1 are stored as bf16
         wjobs = (ReduceJob * 4)()
-        call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(wjobs, ctypes.c_void_p), st)
+        dh1 = datt                                                     # reuse again
+        if precision() == 0:
+            # fp32: the qkv data gradient rides in the weight-gradient batch's launch (both only wait for dqkv)
+            call("cswin_linear_bwd_tail", ptr(dqkv), pq, ptr(dh1), M, 3 * C, C, ctypes.cast(wg, ctypes.c_void_p), 4,
+                 ctypes.cast(wjobs, ctypes.c_void_p), st)
+        else:
+            call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(wjobs, ctypes.c_void_p), st)
+            call("cswin_linear_bwd_data", ptr(dqkv), pq, ptr(dh1), None, 0, None, None, 1, None, M, 3 * C, C, precision(), (1 if s16 else 0) | fq, st)
         for slot, ji in enumerate((0, 1, 3, 4)):
             jobs[ji] = wjobs[slot]
-        dh1 = datt                                                     # reuse again
-        call("cswin_linear_bwd_data", ptr(dqkv), pq, ptr(dh1), None, 0, None, None, 1, None, M, 3 * C, C, precision(), (1 if s16 else 0) | fq, st)
         dx, dg1, dbt1 = torch.empty_like(x), _grad_like(g1, leaf), _grad_at(pb1, (C,), dev)
         dx16 = E16(B, L, C) if s16 else None
         call("cswin_layernorm_bwd", ptr(dh1), ptr(x), ptr(m1), ptr(r1), ptr(g1), ptr(dx1), ptr(dx), ptr(dg1), ptr(dbt1), wsp[5],

@@ -29,7 +29,7 @@ extern "C" {
 /* Bumped whenever a prototype or struct below changes (1: round 1; 2: round 2 -- stream / precision / storage arguments; 3: round 3 --
  * cswin_attn_fwd writes y0, cswin_attn_bwd reads it).  cswin_abi_version() returns the value the library was built with: a consumer
  * compiled against another header must refuse to call it. */
-#define CSWIN_ABI_VERSION 3
+#define CSWIN_ABI_VERSION 4
 
 #define CSWIN_OK 0
 #define CSWIN_ERR_SHAPE (-1)
@@ -158,6 +158,12 @@ typedef struct cswin_wgrad_desc {
 /* Up to 4 independent weight gradients (the four nn.Linear of a CSWinBlock, cswin_unet.py:125,134,17-19) in ONE launch;
  * deferred[0..n) receive their slab reductions (required: run them with cswin_rows_sum_multi). */
 int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* problems, int n, cswin_reduce_job* deferred, void* stream);
+/* The tail of a CSWinBlock's backward (cswin_unet.py:171 / :125 backward): dx (M, K) = dy (M, N) @ w (N, K) -- the qkv Linear's data
+ * gradient, plain fp32 operands -- together with the block's weight gradients (`problems`, `deferred` exactly as above).  Both
+ * only wait for dqkv and neither needs the other: in fp32 with 16-B aligned operands they share ONE launch, otherwise the data
+ * gradient is launched first and the batch follows; the results are those of cswin_linear_bwd_data + cswin_linear_bwd_weight_batch. */
+int cswin_linear_bwd_tail(const float* dy, const float* w, float* dx, int M, int N, int K, const cswin_wgrad_desc* problems, int n,
+                          cswin_reduce_job* deferred, void* stream);
 /* jobs: host array of 1..48 pending reductions (the workspaces they point into must still be alive) */
 int cswin_rows_sum_multi(const cswin_reduce_job* jobs, int njobs, void* stream);
 

@@ -48,7 +48,7 @@ def test_library_loads_and_exports_header_symbols():
             else:
                 assert a.startswith("int") and t is ctypes.c_int, (name, a)
         assert {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "const char*": ctypes.c_char_p}[ret] is res, name
-    assert h.cswin_abi_version() == 3
+    assert h.cswin_abi_version() == 4
     assert isinstance(h.cswin_last_error(), bytes)
 
 

@@ -54,7 +54,7 @@ def ops():
 def test_library_is_the_hip_one():
     from cswin_unet_amd import _lib
     h = _lib.lib()
-    assert h.cswin_abi_version() == 3
+    assert h.cswin_abi_version() == 4
     assert h.cswin_device_ok() == 1, h.cswin_last_error().decode()
     with pytest.raises(_lib.CswinHipError):         # no CPU fallback
         from cswin_unet_amd import ops
@@ -157,6 +157,53 @@ def test_linear_weight_gradient_batch(shapes):
         rel_err(dw, dw_ref, f"wgrad_batch.{i}.dw")
         if db is not None:
             rel_err(db, db_ref, f"wgrad_batch.{i}.db")
+
+
+@pytest.mark.parametrize("M,C", [(4704, 256), (784 * 3, 128), (300, 64), (1176, 512), (196, 96)])
+def test_block_tail_launch_matches_the_two_launches(M, C):
+    """cswin_linear_bwd_tail: the qkv data gradient in the weight-gradient batch's launch (gemm_block_tail_kernel) against
+    cswin_linear_bwd_data followed by cswin_linear_bwd_weight_batch on the same operands: the weight gradients run the same
+    configuration either way (bit-exact), the data gradient another tile shape (same products, other summation order)."""
+    import ctypes
+    from cswin_unet_amd._lib import ReduceJob, WgradDesc, call, lib, ptr, stream
+    dqkv, wq = T(det_normal("tail.dqkv", (M, 3 * C))), T(det_normal("tail.wq", (3 * C, C), 1 / np.sqrt(C)))
+    probs = [(T(det_normal("tail.dy0", (M, C))), T(det_normal("tail.x0", (M, 4 * C))), True),     # fc2
+             (T(det_normal("tail.dy1", (M, 4 * C))), T(det_normal("tail.x1", (M, C))), True),     # fc1
+             (T(det_normal("tail.dy2", (M, C))), T(det_normal("tail.x2", (M, C))), False),        # proj, no bias
+             (dqkv, T(det_normal("tail.x3", (M, C))), True)]                                       # qkv
+    rs = T(np.array([0.0, 1.25, 0.5, 1.0], np.float32))
+    rps = (M + 3) // 4
+
+    def run(merged):
+        wg, jobs, keep, outs = (WgradDesc * 4)(), (ReduceJob * 4)(), [], []
+        for i, (dy, x, with_bias) in enumerate(probs):
+            N_, K = dy.shape[1], x.shape[1]
+            dw, db = torch.empty(N_, K, device=DEV), (torch.empty(N_, device=DEV) if with_bias else None)
+            nbytes = lib().cswin_linear_bwd_weight_workspace(M, N_, K)
+            ws = torch.empty(nbytes // 4 + 4, device=DEV)
+            keep.append(ws)
+            wg[i].dy, wg[i].x, wg[i].row_scale = dy.data_ptr(), x.data_ptr(), (rs.data_ptr() if i == 0 else None)
+            wg[i].dw, wg[i].dbias, wg[i].workspace, wg[i].ws_bytes = dw.data_ptr(), (db.data_ptr() if with_bias else None), ws.data_ptr(), nbytes
+            wg[i].rows_per_sample, wg[i].M, wg[i].N, wg[i].K = rps, M, N_, K
+            outs += [dw] + ([db] if with_bias else [])
+        dx = torch.full((M, C), float("nan"), device=DEV)
+        if merged:
+            call("cswin_linear_bwd_tail", ptr(dqkv), ptr(wq), ptr(dx), M, 3 * C, C, ctypes.cast(wg, ctypes.c_void_p), 4,
+                 ctypes.cast(jobs, ctypes.c_void_p), stream())
+        else:
+            call("cswin_linear_bwd_data", ptr(dqkv), ptr(wq), ptr(dx), None, 0, None, None, 1, None, M, 3 * C, C, 0, 0, stream())
+            call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(jobs, ctypes.c_void_p), stream())
+        call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), 4, stream())
+        torch.cuda.synchronize()
+        return dx, outs
+
+    dx1, o1 = run(True)
+    dx0, o0 = run(False)
+    assert bool(torch.isfinite(dx1).all())
+    assert _rel_l2(dx1, dx0) < 1e-6, _rel_l2(dx1, dx0)
+    rel_err(dx1, (dqkv.double() @ wq.double()).float().cpu(), f"tail.dx.{M}x{C}")
+    for a, b in zip(o1, o0):
+        assert torch.equal(a, b)
 
 
 def test_linear_concat_residual_droppath(ops):
