@@ -35,7 +35,7 @@ SIGNATURES = {
     "cswin_linear_bwd_weight_workspace": (SZ, [I, I, I]),
     "cswin_linear_bwd_weight": (I, [P, P, P, I, P, I, P, P, P, SZ, I, I, I, P, I, P]),
     "cswin_linear_bwd_weight_batch": (I, [P, I, P, P]),
-    "cswin_linear_bwd_tail": (I, [P, P, P, I, I, I, P, I, P, P]),
+    "cswin_linear_bwd_tail": (I, [P, P, P, I, I, I, P, I, P, P, I, P]),
     "cswin_rows_sum_multi": (I, [P, I, P]),
     "cswin_conv_tok_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "cswin_conv_tok_bwd_data": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
@@ -48,7 +48,7 @@ SIGNATURES = {
     "cswin_tokens_to_nchw": (I, [P, P, I, I, I, I, I, P]),
     "cswin_carafe_fwd": (I, [P, P, P, P, P, I, I, I, I, I, P]),
     "cswin_carafe_bwd_workspace": (SZ, [I, I, I, I, I]),
-    "cswin_carafe_bwd": (I, [P, P, P, P, P, P, P, SZ, I, I, I, I, I, P]),
+    "cswin_carafe_bwd": (I, [P, P, P, P, P, P, P, SZ, I, I, I, I, I, P, P]),
     "cswin_loss_workspace": (SZ, [I, I, L]),
     "cswin_loss_sums": (I, [P, P, P, P, SZ, I, I, L, I, P]),
     "cswin_loss_finalize": (I, [P, P, P, D, I, F, F, P, P]),

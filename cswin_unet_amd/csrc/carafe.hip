@@ -401,7 +401,8 @@ size_t cswin_carafe_bwd_workspace(int B, int H, int W, int Cz, int S) {
 
 // dout (B, (S*H)*(S*W), Cz) -> de (B, H*W, 9*S*S), dz (B, H*W, Cz), dbias (Cz) (may be NULL)
 int cswin_carafe_bwd(const float* dout, const float* z, const float* wt_save, float* de, float* dz, float* dbias,
-                     void* workspace, size_t ws_bytes, int B, int H, int W, int Cz, int S, void* stream) {
+                     void* workspace, size_t ws_bytes, int B, int H, int W, int Cz, int S, cswin_reduce_job* deferred, void* stream) {
+    if (deferred) *deferred = cswin_reduce_job{};          // part == NULL: nothing pending (no bias)
     CSWIN_REQUIRE(dout && z && wt_save && de && dz, CSWIN_ERR_SHAPE, "carafe_bwd: null pointer");
     CSWIN_REQUIRE(carafe_args_ok(B, H, W, Cz, S), CSWIN_ERR_UNSUPPORTED, "carafe_bwd: unsupported shape");
     CSWIN_REQUIRE(!dbias || (workspace && ws_bytes >= cswin_carafe_bwd_workspace(B, H, W, Cz, S)), CSWIN_ERR_WORKSPACE, "carafe_bwd: workspace too small");
@@ -415,7 +416,7 @@ int cswin_carafe_bwd(const float* dout, const float* z, const float* wt_save, fl
                            dbias ? (float*)workspace : nullptr, B, H, W, tx, ty);
         CSWIN_LAUNCH_CHECK();
         if (dbias) {
-            launch_rows_sum((const float*)workspace, dbias, nullptr, 0, Cz, nblk, Cz, st);
+            reduce_now_or_defer(cswin_reduce_job{(const float*)workspace, dbias, nullptr, 0, Cz, Cz, nblk, 0, 0, 0}, deferred, st);
             CSWIN_LAUNCH_CHECK();
         }
         return CSWIN_OK;
@@ -432,12 +433,12 @@ int cswin_carafe_bwd(const float* dout, const float* z, const float* wt_save, fl
     }
     CSWIN_LAUNCH_CHECK();
     if (bias_in_e) {
-        launch_rows_sum((const float*)workspace, dbias, nullptr, 0, Cz, eblk, Cz, st);
+        reduce_now_or_defer(cswin_reduce_job{(const float*)workspace, dbias, nullptr, 0, Cz, Cz, eblk, 0, 0, 0}, deferred, st);
         CSWIN_LAUNCH_CHECK();
     } else if (dbias) {
         int nblk = colsum_blocks(items, Cz);
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, dout, (float*)workspace, items, Cz);
-        launch_rows_sum((const float*)workspace, dbias, nullptr, 0, Cz, nblk, Cz, st);
+        reduce_now_or_defer(cswin_reduce_job{(const float*)workspace, dbias, nullptr, 0, Cz, Cz, nblk, 0, 0, 0}, deferred, st);
         CSWIN_LAUNCH_CHECK();
     }
     return CSWIN_OK;

@@ -250,18 +250,48 @@ static inline void launch_rows_sum(const float* part, float* out, float* out2, l
     hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((n + cols - 1) / cols)), dim3(256), 0, st, job);
 }
 
-static __global__ __launch_bounds__(256) void rows_sum_multi_kernel(ReduceJobs J) {
-    __shared__ float red[RS_G][RS_COLS + 1];
-    int lo = 0, hi = J.njobs - 1;                    // the job of this workgroup: last k with first_block[k] <= blockIdx.x
+// workgroup `blk` of a job table (256 threads; `red` = 16 x 65 floats of LDS): the job is the last k with first_block[k] <= blk
+__device__ __forceinline__ void rows_sum_dispatch(const cswin_reduce_job* j, const int* first_block, int njobs, int blk,
+                                                  float (*red)[RS_COLS + 1]) {
+    int lo = 0, hi = njobs - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if ((int)blockIdx.x >= J.first_block[mid]) lo = mid;
+        if (blk >= first_block[mid]) lo = mid;
         else hi = mid - 1;
     }
     const int k = lo;
-    if (J.j[k].conv_kk) rows_sum_conv_block(J.j[k], blockIdx.x - J.first_block[k], red);
-    else if (J.j[k].reserved & 2) rows_sum_few(J.j[k], blockIdx.x - J.first_block[k]);
-    else rows_sum_block(J.j[k], blockIdx.x - J.first_block[k], red);
+    if (j[k].conv_kk) rows_sum_conv_block(j[k], blk - first_block[k], red);
+    else if (j[k].reserved & 2) rows_sum_few(j[k], blk - first_block[k]);
+    else rows_sum_block(j[k], blk - first_block[k], red);
+}
+
+static __global__ __launch_bounds__(256) void rows_sum_multi_kernel(ReduceJobs J) {
+    __shared__ float red[RS_G][RS_COLS + 1];
+    rows_sum_dispatch(J.j, J.first_block, J.njobs, (int)blockIdx.x, red);
+}
+
+// Reductions that ride at the end of another kernel's grid (gemm_block_tail_kernel): memory-bound workgroups of a few hundred
+// cycles each beside matrix-pipe-bound ones, instead of a launch of their own
+constexpr int CSWIN_TAIL_RIDER_JOBS = 16;
+struct ReduceRiders {
+    cswin_reduce_job j[CSWIN_TAIL_RIDER_JOBS];
+    int first_block[CSWIN_TAIL_RIDER_JOBS + 1];
+    int njobs;
+};
+// validate + flag the jobs of a table and give every job its workgroup range; returns the number of workgroups or -1
+static inline int fill_reduce_table(const cswin_reduce_job* jobs, int njobs, cswin_reduce_job* out, int* first_block) {
+    int blocks = 0;
+    for (int i = 0; i < njobs; ++i) {
+        if (!(jobs[i].part && jobs[i].out && jobs[i].n > 0 && jobs[i].rows > 0)) return -1;
+        if ((jobs[i].conv_kk == 0) != (jobs[i].conv_cin == 0) || jobs[i].conv_kk < 0) return -1;
+        out[i] = jobs[i];
+        const int few = reduce_job_few_ok(jobs[i]);
+        out[i].reserved = reduce_job_vec_ok(jobs[i]) | (few ? 2 : 0);
+        first_block[i] = blocks;
+        blocks += few ? (int)((jobs[i].n + RS_FEW_COLS - 1) / RS_FEW_COLS) : (int)((jobs[i].n + RS_COLS - 1) / RS_COLS);
+    }
+    first_block[njobs] = blocks;
+    return blocks;
 }
 
 // run `job` now, or hand it to the caller (deferred != NULL) to be batched by cswin_rows_sum_multi

@@ -590,13 +590,20 @@ struct BlockTail {
     Epilogue de;
     int dM, dN, dR, drps, dtm, dtn, nd;
     WgradBatch w;
+    ReduceRiders r;          // pending slab reductions of EARLIER launches (the previous block's): the grid's last workgroups
 };
 __global__ __launch_bounds__(512) void gemm_block_tail_kernel(BlockTail t) {
     constexpr int L0 = gemm_lds_floats<64, 64, 64, 2, true, false>(), L1 = gemm_lds_floats<64, 64, 64, 2, false, false>();
     __shared__ __attribute__((aligned(16))) float lds[L0 > L1 ? L0 : L1];
     const WgradBatch& b = t.w;
     const int nw = b.first[b.n];
-    if ((int)blockIdx.x >= nw) {           // the data gradient's tiles come LAST: they fill the weight gradients' tail
+    if ((int)blockIdx.x >= nw + t.nd) {    // riders: 256-thread reduction workgroups (the upper four waves leave)
+        if (threadIdx.x >= 256) return;
+        static_assert(sizeof(lds) >= sizeof(float) * RS_G * (RS_COLS + 1), "reduction scratch");
+        rows_sum_dispatch(t.r.j, t.r.first_block, t.r.njobs, (int)blockIdx.x - nw - t.nd, reinterpret_cast<float(*)[RS_COLS + 1]>(lds));
+        return;
+    }
+    if ((int)blockIdx.x >= nw) {           // the data gradient's tiles come after the weight gradients': they fill their tail
         gemm_body<64, 64, 64, 2, true, false, 4, EPI_PLAIN, false, 0, PlainSrc, PlainSrc>(
             lds, t.dA, t.dB, t.de, t.dM, t.dN, t.dR, t.drps, t.dtm, t.dtn, (int)blockIdx.x - nw, t.nd, (int)blockIdx.x);
         return;
@@ -834,10 +841,11 @@ size_t cswin_linear_bwd_weight_workspace(int M, int N, int K) {
 }
 
 int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferred, void* stream);
+int cswin_rows_sum_multi(const cswin_reduce_job* jobs, int njobs, void* stream);
 }  // extern "C"
 namespace {
 // a plain fp32 data gradient dx[M,K] = dy[M,N] @ w[N,K] that may ride in the weight-gradient batch's launch (cswin_linear_bwd_tail)
-struct DgradRider { const float* dy; const float* w; float* dx; int M, N, K; };
+struct DgradRider { const float* dy; const float* w; float* dx; int M, N, K; const cswin_reduce_job* jobs; int njobs; };
 int wgrad_batch_impl(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferred, const DgradRider* rider, void* stream);
 }  // namespace
 extern "C" {
@@ -908,9 +916,11 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
 // and the block's weight gradients as cswin_linear_bwd_weight_batch takes them.  In fp32 with aligned operands both run in ONE
 // launch (gemm_block_tail_kernel); otherwise the data gradient is launched first and the batch follows -- same results either way.
 int cswin_linear_bwd_tail(const float* dy, const float* w, float* dx, int M, int N, int K, const cswin_wgrad_desc* d, int n,
-                          cswin_reduce_job* deferred, void* stream) {
+                          cswin_reduce_job* deferred, const cswin_reduce_job* pending, int npending, void* stream) {
     CSWIN_REQUIRE(dy && w && dx && M > 0 && N > 0 && K > 0, CSWIN_ERR_SHAPE, "linear_bwd_tail: bad data-gradient arguments");
-    DgradRider r = {dy, w, dx, M, N, K};
+    CSWIN_REQUIRE(npending >= 0 && npending <= CSWIN_TAIL_RIDER_JOBS && (npending == 0 || pending), CSWIN_ERR_SHAPE,
+                  "linear_bwd_tail: 0..%d pending reductions", CSWIN_TAIL_RIDER_JOBS);
+    DgradRider r = {dy, w, dx, M, N, K, pending, npending};
     return wgrad_batch_impl(d, n, deferred, &r, stream);
 }
 
@@ -932,10 +942,14 @@ int wgrad_batch_impl(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferre
     }
     const bool ride = rider && fast && precision == 0 && rider->N % 4 == 0 && rider->K % 4 == 0 && aligned16(rider->dy) &&
                       aligned16(rider->w) && aligned16(rider->dx) && cswin_tuning().gemm_tail_merge;
-    if (rider && !ride) {                   // the data gradient as a launch of its own, then the batch as usual
+    if (rider && !ride) {                   // the data gradient (and the pending reductions) as launches of their own, then the batch as usual
         int rc = cswin_linear_bwd_data(rider->dy, rider->w, rider->dx, nullptr, 0, nullptr, nullptr, 1, nullptr, rider->M, rider->N,
                                        rider->K, precision == 1 ? 1 : 0, 0, stream);
         if (rc) return rc;
+        if (rider->njobs > 0) {
+            rc = cswin_rows_sum_multi(rider->jobs, rider->njobs, stream);
+            if (rc) return rc;
+        }
     }
     if (!fast) {
         for (int i = 0; i < n; ++i) CSWIN_REQUIRE(d[i].io_bf16 == 0, CSWIN_ERR_ALIGN, "linear_bwd_weight_batch: bf16 storage needs N, K multiples of 4 and 16-B alignment");
@@ -1028,8 +1042,14 @@ int wgrad_batch_impl(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferre
         t.dtm = cdiv(rider->M, 64); t.dtn = cdiv(rider->K, 64);
         t.nd = t.dtm * t.dtn;
         t.w = b;
+        int rblocks = 0;
+        if (rider->njobs > 0) {
+            rblocks = fill_reduce_table(rider->jobs, rider->njobs, t.r.j, t.r.first_block);
+            CSWIN_REQUIRE(rblocks >= 0, CSWIN_ERR_SHAPE, "linear_bwd_tail: bad pending reduction");
+            t.r.njobs = rider->njobs;
+        }
         static_assert(sizeof(BlockTail) <= 4096, "kernel argument block");
-        hipLaunchKernelGGL(gemm_block_tail_kernel, dim3(t.nd + blocks), dim3(512), 0, (hipStream_t)stream, t);
+        hipLaunchKernelGGL(gemm_block_tail_kernel, dim3(blocks + t.nd + rblocks), dim3(512), 0, (hipStream_t)stream, t);
     } else if (precision == 1) {
         hipLaunchKernelGGL(gemm_wgrad_batch_kernel<1>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, b);
     } else {
@@ -1174,17 +1194,8 @@ int cswin_conv_tok_bwd_weight(const float* dy, const float* x, float* dw_perm, f
 int cswin_rows_sum_multi(const cswin_reduce_job* jobs, int njobs, void* stream) {
     CSWIN_REQUIRE(jobs && njobs > 0 && njobs <= CSWIN_MAX_REDUCE_JOBS, CSWIN_ERR_SHAPE, "rows_sum_multi: 1..%d jobs", CSWIN_MAX_REDUCE_JOBS);
     ReduceJobs J = {};
-    int blocks = 0;
-    for (int i = 0; i < njobs; ++i) {
-        CSWIN_REQUIRE(jobs[i].part && jobs[i].out && jobs[i].n > 0 && jobs[i].rows > 0, CSWIN_ERR_SHAPE, "rows_sum_multi: bad job %d", i);
-        J.j[i] = jobs[i];
-        CSWIN_REQUIRE((jobs[i].conv_kk == 0) == (jobs[i].conv_cin == 0) && jobs[i].conv_kk >= 0, CSWIN_ERR_SHAPE, "rows_sum_multi: job %d: conv_kk / conv_cin", i);
-        const int few = reduce_job_few_ok(jobs[i]);
-        J.j[i].reserved = reduce_job_vec_ok(jobs[i]) | (few ? 2 : 0);
-        J.first_block[i] = blocks;
-        blocks += few ? (int)((jobs[i].n + RS_FEW_COLS - 1) / RS_FEW_COLS) : (int)((jobs[i].n + RS_COLS - 1) / RS_COLS);
-    }
-    J.first_block[njobs] = blocks;
+    const int blocks = fill_reduce_table(jobs, njobs, J.j, J.first_block);
+    CSWIN_REQUIRE(blocks >= 0, CSWIN_ERR_SHAPE, "rows_sum_multi: bad job (part / out / n / rows, or conv_kk without conv_cin)");
     J.njobs = njobs;
     hipLaunchKernelGGL(rows_sum_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, J);
     CSWIN_LAUNCH_CHECK();

@@ -72,6 +72,20 @@ def flush_reductions():
     del keep
 
 
+TAIL_RIDER_JOBS = 16
+
+
+def take_pending_reductions(maxn=TAIL_RIDER_JOBS):
+    """Up to `maxn` queued reductions (oldest first) for a launch that can carry them at the end of its grid (cswin_linear_bwd_tail):
+    (ctypes array or None, count).  The workspaces they read stay in the queue's keep-alive list until the next flush."""
+    n = min(len(_rq["jobs"]), maxn) if _rq["on"] else 0
+    if n == 0:
+        return None, 0
+    chunk = _rq["jobs"][:n]
+    del _rq["jobs"][:n]
+    return (ReduceJob * n)(*chunk), n
+
+
 def _reduce_jobs(jobs, keep, leaf=True):
     """jobs: ReduceJob structs filled by entry points called with `deferred`; keep: the workspaces they read.  leaf: every output
     is the gradient of a leaf parameter (nothing else in this backward pass reads it), so the jobs may wait for the flush."""
@@ -653,8 +667,9 @@ class _CSWinBlock(Function):
         dh1 = datt                                                     # reuse again
         if precision() == 0:
             # fp32: the qkv data gradient rides in the weight-gradient batch's launch (both only wait for dqkv)
+            pend, npend = take_pending_reductions()          # the previous blocks' slab reductions ride at the end of this grid
             call("cswin_linear_bwd_tail", ptr(dqkv), pq, ptr(dh1), M, 3 * C, C, ctypes.cast(wg, ctypes.c_void_p), 4,
-                 ctypes.cast(wjobs, ctypes.c_void_p), st)
+                 ctypes.cast(wjobs, ctypes.c_void_p), ctypes.cast(pend, ctypes.c_void_p) if npend else None, npend, st)
         else:
             call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(wjobs, ctypes.c_void_p), st)
             call("cswin_linear_bwd_data", ptr(dqkv), pq, ptr(dh1), None, 0, None, None, 1, None, M, 3 * C, C, precision(), (1 if s16 else 0) | fq, st)
@@ -825,7 +840,10 @@ class _CarafeReassemble(Function):
         db = _grad_at(ctx.bias_ptr, (Cz,), z.device) if has_b else None
         nbytes = lib().cswin_carafe_bwd_workspace(B, H, W, Cz, S)
         ws = _ws(nbytes, z.device)
-        call("cswin_carafe_bwd", ptr(dout), ptr(z), ptr(wt), ptr(de), ptr(dz), ptr(db), ptr(ws), nbytes, B, H, W, Cz, S, stream())
+        job = (ReduceJob * 1)()
+        call("cswin_carafe_bwd", ptr(dout), ptr(z), ptr(wt), ptr(de), ptr(dz), ptr(db), ptr(ws), nbytes, B, H, W, Cz, S,
+             ctypes.cast(job, ctypes.c_void_p), stream())
+        _reduce_jobs(job, [ws], leaf=ctx.bias_ptr != 0)      # the bias gradient's partial sums: queued when the bias is a leaf parameter
         return de, dz, db, None, None, None
 
 

@@ -161,9 +161,11 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* problems, int n, cswin
 /* The tail of a CSWinBlock's backward (cswin_unet.py:171 / :125 backward): dx (M, K) = dy (M, N) @ w (N, K) -- the qkv Linear's data
  * gradient, plain fp32 operands -- together with the block's weight gradients (`problems`, `deferred` exactly as above).  Both
  * only wait for dqkv and neither needs the other: in fp32 with 16-B aligned operands they share ONE launch, otherwise the data
- * gradient is launched first and the batch follows; the results are those of cswin_linear_bwd_data + cswin_linear_bwd_weight_batch. */
+ * gradient is launched first and the batch follows; the results are those of cswin_linear_bwd_data + cswin_linear_bwd_weight_batch.
+ * pending[0..npending), npending <= 16: reductions left pending by EARLIER calls (not this call's `deferred`): they are run by
+ * this launch's last workgroups (or by a cswin_rows_sum_multi launch on the two-launch path) and must not be run again. */
 int cswin_linear_bwd_tail(const float* dy, const float* w, float* dx, int M, int N, int K, const cswin_wgrad_desc* problems, int n,
-                          cswin_reduce_job* deferred, void* stream);
+                          cswin_reduce_job* deferred, const cswin_reduce_job* pending, int npending, void* stream);
 /* jobs: host array of 1..48 pending reductions (the workspaces they point into must still be alive) */
 int cswin_rows_sum_multi(const cswin_reduce_job* jobs, int njobs, void* stream);
 
@@ -202,8 +204,10 @@ int cswin_tokens_to_nchw(const float* x, float* y, int B, int C, int H, int W, i
 int cswin_carafe_fwd(const float* e, const float* z, const float* bias, float* out, float* wt_save, int B, int H,
                      int W, int Cz, int S, void* stream);
 size_t cswin_carafe_bwd_workspace(int B, int H, int W, int Cz, int S);
+/* dbias (Cz, may be NULL) = column sums of dout, formed from per-workgroup partial sums in `workspace`; `deferred` as for
+ * layernorm_bwd (NULL: reduced immediately; else the job is returned, zeroed when there is no bias) */
 int cswin_carafe_bwd(const float* dout, const float* z, const float* wt_save, float* de, float* dz, float* dbias,
-                     void* workspace, size_t ws_bytes, int B, int H, int W, int Cz, int S, void* stream);
+                     void* workspace, size_t ws_bytes, int B, int H, int W, int Cz, int S, cswin_reduce_job* deferred, void* stream);
 
 /* ---- loss of the training step: 0.4*CE + 0.6*Dice (trainer.py:55-57, utils.py:9-45) ----
  * logits (B, ncls, HW) fp32, labels (B, HW) int64.  sums[1 + 3*ncls] = {sum -log p[label], intersect_c, y_sum_c,

@@ -187,14 +187,30 @@ def test_block_tail_launch_matches_the_two_launches(M, C):
             wg[i].rows_per_sample, wg[i].M, wg[i].N, wg[i].K = rps, M, N_, K
             outs += [dw] + ([db] if with_bias else [])
         dx = torch.full((M, C), float("nan"), device=DEV)
+        # three reductions left pending by "earlier" launches ride along: slabs of few rows (the weight-gradient form), of many
+        # rows (LayerNorm dgamma / dbeta form, with a second output) and a short ragged one
+        pend = (ReduceJob * 3)()
+        pouts = []
+        for k, (rows, n, nf) in enumerate(((6, 8192, 8192), (300, 512, 256), (5, 37, 37))):
+            part, o1 = T(det_normal(f"tail.part{k}", (rows, n))), torch.full((nf,), float("nan"), device=DEV)
+            o2 = torch.full((n - nf,), float("nan"), device=DEV) if n > nf else None
+            pend[k].part, pend[k].out, pend[k].out2 = part.data_ptr(), o1.data_ptr(), (o2.data_ptr() if o2 is not None else None)
+            pend[k].n_first, pend[k].n, pend[k].stride, pend[k].rows = nf, n, n, rows
+            keep.append(part)
+            pouts.append((part, o1, o2, nf))
         if merged:
             call("cswin_linear_bwd_tail", ptr(dqkv), ptr(wq), ptr(dx), M, 3 * C, C, ctypes.cast(wg, ctypes.c_void_p), 4,
-                 ctypes.cast(jobs, ctypes.c_void_p), stream())
+                 ctypes.cast(jobs, ctypes.c_void_p), ctypes.cast(pend, ctypes.c_void_p), len(pend), stream())
         else:
             call("cswin_linear_bwd_data", ptr(dqkv), ptr(wq), ptr(dx), None, 0, None, None, 1, None, M, 3 * C, C, 0, 0, stream())
             call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(jobs, ctypes.c_void_p), stream())
+            call("cswin_rows_sum_multi", ctypes.cast(pend, ctypes.c_void_p), 3, stream())
         call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), 4, stream())
         torch.cuda.synchronize()
+        for part, o1, o2, nf in pouts:
+            ref = part.double().sum(0)
+            assert _rel_l2(o1, ref[:nf]) < 1e-6 and (o2 is None or _rel_l2(o2, ref[nf:]) < 1e-6)
+            outs += [o1] + ([o2] if o2 is not None else [])
         return dx, outs
 
     dx1, o1 = run(True)
