@@ -34,7 +34,7 @@ SIGNATURES = {
     "cswin_linear_bwd_data": (I, [P, P, P, P, I, P, P, I, P, I, I, I, I, I, P]),
     "cswin_linear_bwd_weight_workspace": (SZ, [I, I, I]),
     "cswin_linear_bwd_weight": (I, [P, P, P, I, P, I, P, P, P, SZ, I, I, I, P, I, P]),
-    "cswin_linear_bwd_weight_batch": (I, [P, I, P, P]),
+    "cswin_linear_bwd_weight_batch": (I, [P, I, P, P, I, P]),
     "cswin_linear_bwd_tail": (I, [P, P, P, I, I, I, P, I, P, P, I, P]),
     "cswin_rows_sum_multi": (I, [P, I, P]),
     "cswin_conv_tok_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),

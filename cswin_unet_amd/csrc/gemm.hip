@@ -27,7 +27,8 @@
 // both operands stored as bf16 (gemm16.hip); 0 = launched, 1 = not covered
 int cswin_gemm16(int mode, int epi_mode, const void* A, const void* B, const void* epilogue, int M, int NO, int R, void* stream);
 // wgrad16.hip: bf16-operand weight gradients with transposing LDS reads (bf16 matmul mode)
-int cswin_wgrad16_batch(const cswin_wgrad_desc* d, int n, const int* splits, const int* rows_per_split, void* stream, long long* stamps);
+int cswin_wgrad16_batch(const cswin_wgrad_desc* d, int n, const int* splits, const int* rows_per_split, const cswin_reduce_job* pending,
+                        int npending, void* stream, long long* stamps);
 
 namespace {
 
@@ -840,7 +841,8 @@ size_t cswin_linear_bwd_weight_workspace(int M, int N, int K) {
     return (size_t)(s0 > s1 ? s0 : s1) * ((size_t)N * K + N) * sizeof(float);
 }
 
-int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferred, void* stream);
+int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferred, const cswin_reduce_job* pending, int npending,
+                                  void* stream);
 int cswin_rows_sum_multi(const cswin_reduce_job* jobs, int njobs, void* stream);
 }  // extern "C"
 namespace {
@@ -865,7 +867,7 @@ int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, in
         // bf16 mode: the transposing-read kernel (wgrad16.hip) through the batch entry, as a batch of one
         cswin_wgrad_desc d1 = {dy, x, row_scale, dw, dbias, workspace, ws_bytes, rows_per_sample, M, N, K, 1, 0};
         cswin_reduce_job job;
-        int rc = cswin_linear_bwd_weight_batch(&d1, 1, &job, stream);
+        int rc = cswin_linear_bwd_weight_batch(&d1, 1, &job, nullptr, 0, stream);
         if (rc) return rc;
         reduce_now_or_defer(job, deferred, st);
         CSWIN_LAUNCH_CHECK();
@@ -908,8 +910,12 @@ int cswin_linear_bwd_weight(const float* dy, const float* x, const float* x2, in
 // n (<= 4) weight gradients without concat sources in one launch (see gemm_wgrad_batch_kernel); deferred[i] receives problem
 // i's slab reduction (run them with cswin_rows_sum_multi).  Falls back to separate launches when a problem is not 16-B
 // aligned / a multiple of 4 in N and K.
-int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferred, void* stream) {
-    return wgrad_batch_impl(d, n, deferred, nullptr, stream);
+int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferred, const cswin_reduce_job* pending, int npending,
+                                  void* stream) {
+    CSWIN_REQUIRE(npending >= 0 && npending <= CSWIN_TAIL_RIDER_JOBS && (npending == 0 || pending), CSWIN_ERR_SHAPE,
+                  "linear_bwd_weight_batch: 0..%d pending reductions", CSWIN_TAIL_RIDER_JOBS);
+    DgradRider r = {nullptr, nullptr, nullptr, 0, 0, 0, pending, npending};
+    return wgrad_batch_impl(d, n, deferred, npending > 0 ? &r : nullptr, stream);
 }
 
 // The tail of a CSWinBlock's backward: dx[M,K] = dy[M,N] @ w[N,K] (the qkv Linear's data gradient, plain fp32, no epilogue extras)
@@ -940,14 +946,20 @@ int wgrad_batch_impl(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferre
         CSWIN_REQUIRE(d[i].workspace && d[i].ws_bytes >= need, CSWIN_ERR_WORKSPACE, "linear_bwd_weight_batch: workspace %zu < %zu", d[i].ws_bytes, need);
         fast = fast && d[i].N % 4 == 0 && d[i].K % 4 == 0 && aligned16(d[i].dy) && aligned16(d[i].x) && aligned16(d[i].workspace);
     }
-    const bool ride = rider && fast && precision == 0 && rider->N % 4 == 0 && rider->K % 4 == 0 && aligned16(rider->dy) &&
-                      aligned16(rider->w) && aligned16(rider->dx) && cswin_tuning().gemm_tail_merge;
+    const bool has_dgrad = rider && rider->dy;
+    const bool merge_on = cswin_tuning().gemm_tail_merge != 0;                                                  // tuning aid
+    const bool ride = rider && merge_on && fast && precision == 0 &&
+                      (!has_dgrad || (rider->N % 4 == 0 && rider->K % 4 == 0 && aligned16(rider->dy) && aligned16(rider->w) && aligned16(rider->dx)));
+    const bool w16_path = fast && precision == 1 && (cswin_tuning().wgrad16_on || d[0].io_bf16 || (n > 1 && d[1].io_bf16) || (n > 2 && d[2].io_bf16) || (n > 3 && d[3].io_bf16));
+    const bool jobs_ride16 = rider && merge_on && w16_path && rider->njobs > 0;       // bf16 mode: the reductions ride in wgrad16's grid
     if (rider && !ride) {                   // the data gradient (and the pending reductions) as launches of their own, then the batch as usual
-        int rc = cswin_linear_bwd_data(rider->dy, rider->w, rider->dx, nullptr, 0, nullptr, nullptr, 1, nullptr, rider->M, rider->N,
-                                       rider->K, precision == 1 ? 1 : 0, 0, stream);
-        if (rc) return rc;
-        if (rider->njobs > 0) {
-            rc = cswin_rows_sum_multi(rider->jobs, rider->njobs, stream);
+        if (has_dgrad) {
+            int rc = cswin_linear_bwd_data(rider->dy, rider->w, rider->dx, nullptr, 0, nullptr, nullptr, 1, nullptr, rider->M, rider->N,
+                                           rider->K, precision == 1 ? 1 : 0, 0, stream);
+            if (rc) return rc;
+        }
+        if (rider->njobs > 0 && !jobs_ride16) {
+            int rc = cswin_rows_sum_multi(rider->jobs, rider->njobs, stream);
             if (rc) return rc;
         }
     }
@@ -960,8 +972,7 @@ int wgrad_batch_impl(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferre
         }
         return CSWIN_OK;
     }
-    const int w16_off = !cswin_tuning().wgrad16_on;                                                  // tuning aid
-    if (precision == 1 && (!w16_off || d[0].io_bf16 || (n > 1 && d[1].io_bf16) || (n > 2 && d[2].io_bf16) || (n > 3 && d[3].io_bf16))) {
+    if (w16_path) {
         // bf16 operands: 128 x 128 tiles, ~3 workgroups per CU over the whole batch (load-bound: see wgrad16.hip)
         // Workgroups are shared out in proportion to the work (rows x tiles), so that every workgroup of the launch walks the same
         // number of rows: with equal shares per problem the C x C problem's workgroups finished after 10 k cycles and the C x 4C
@@ -984,7 +995,8 @@ int wgrad_batch_impl(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferre
             const long nk = (long)N * K;
             deferred[i] = cswin_reduce_job{(const float*)d[i].workspace, d[i].dw, d[i].dbias, nk, nk + (d[i].dbias ? N : 0), nk + N, splits[i], 0};
         }
-        cswin_wgrad16_batch(d, n, splits, rps, stream, g_stamps);
+        CSWIN_REQUIRE(cswin_wgrad16_batch(d, n, splits, rps, jobs_ride16 ? rider->jobs : nullptr, jobs_ride16 ? rider->njobs : 0, stream, g_stamps) == 0,
+                      CSWIN_ERR_SHAPE, "linear_bwd_weight_batch: bad pending reduction");
         CSWIN_LAUNCH_CHECK();
         return CSWIN_OK;
     }
@@ -1033,14 +1045,16 @@ int wgrad_batch_impl(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferre
     b.n = n;
     if (ride) {
         BlockTail t = {};
-        Epilogue e = plain_epilogue(rider->dx, rider->K);
-        e.vec_store = epilogue_vec_ok(e, rider->K);
-        t.dA = PlainSrc{rider->dy, rider->N, rider->M, rider->N, nullptr, 1, 0};
-        t.dB = PlainSrc{rider->w, rider->K, rider->N, rider->K, nullptr, 1, 0};      // S(i = n (reduction), j = k)
-        t.de = e;
-        t.dM = rider->M; t.dN = rider->K; t.dR = rider->N; t.drps = cdiv(rider->N, BKMAX) * BKMAX;
-        t.dtm = cdiv(rider->M, 64); t.dtn = cdiv(rider->K, 64);
-        t.nd = t.dtm * t.dtn;
+        if (has_dgrad) {
+            Epilogue e = plain_epilogue(rider->dx, rider->K);
+            e.vec_store = epilogue_vec_ok(e, rider->K);
+            t.dA = PlainSrc{rider->dy, rider->N, rider->M, rider->N, nullptr, 1, 0};
+            t.dB = PlainSrc{rider->w, rider->K, rider->N, rider->K, nullptr, 1, 0};      // S(i = n (reduction), j = k)
+            t.de = e;
+            t.dM = rider->M; t.dN = rider->K; t.dR = rider->N; t.drps = cdiv(rider->N, BKMAX) * BKMAX;
+            t.dtm = cdiv(rider->M, 64); t.dtn = cdiv(rider->K, 64);
+            t.nd = t.dtm * t.dtn;
+        }
         t.w = b;
         int rblocks = 0;
         if (rider->njobs > 0) {

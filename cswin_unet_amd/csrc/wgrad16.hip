@@ -41,6 +41,7 @@ struct W16Batch {
     int first[W16_MAXP + 1];
     int n;
     long long* stamps;              // debug (cswin_debug_set_stamps): [workgroup][8] s_memtime / realtime stamps of thread 0, or NULL
+    ReduceRiders r;                 // pending slab reductions of earlier launches: the grid's last workgroups (common.h)
 };
 
 // byte offset of 16-B chunk `ch` (8 bf16) of row `row` inside a [rows][128] bf16 image
@@ -374,6 +375,11 @@ __device__ __forceinline__ void wgrad16_dma_tile(const W16Problem& P, const int 
 
 __global__ __launch_bounds__(256, 3) void wgrad16_kernel(W16Batch b) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[W16_LDS];
+    if ((int)blockIdx.x >= b.first[b.n]) {
+        static_assert(W16_LDS >= (int)sizeof(float) * RS_G * (RS_COLS + 1), "reduction scratch");
+        rows_sum_dispatch(b.r.j, b.r.first_block, b.r.njobs, (int)blockIdx.x - b.first[b.n], reinterpret_cast<float(*)[RS_COLS + 1]>(lds));
+        return;
+    }
     int pi = 0;
     while (pi + 1 < b.n && (int)blockIdx.x >= b.first[pi + 1]) ++pi;
     const W16Problem& P = b.p[pi];
@@ -396,8 +402,10 @@ __global__ __launch_bounds__(256, 3) void wgrad16_kernel(W16Batch b) {
 }  // namespace
 
 // Internal entry used by gemm.hip's cswin_linear_bwd_weight_batch in bf16 matmul mode.  Problems must be 16-B aligned with
-// N % 4 == K % 4 == 0 (the caller checks).  splits[i] <= what problem i's workspace holds.  Returns 0.
-int cswin_wgrad16_batch(const cswin_wgrad_desc* d, int n, const int* splits, const int* rows_per_split, void* stream, long long* stamps) {
+// N % 4 == K % 4 == 0 (the caller checks).  splits[i] <= what problem i's workspace holds.  pending[0..npending): reductions of
+// earlier launches that ride as this grid's last workgroups.  Returns 0 (1: a bad pending job).
+int cswin_wgrad16_batch(const cswin_wgrad_desc* d, int n, const int* splits, const int* rows_per_split, const cswin_reduce_job* pending,
+                        int npending, void* stream, long long* stamps) {
     W16Batch b = {};
     int blocks = 0;
     for (int i = 0; i < n; ++i) {
@@ -422,6 +430,13 @@ int cswin_wgrad16_batch(const cswin_wgrad_desc* d, int n, const int* splits, con
     b.first[n] = blocks;
     b.n = n;
     b.stamps = stamps;
-    hipLaunchKernelGGL(wgrad16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+    int rblocks = 0;
+    if (npending > 0) {
+        rblocks = fill_reduce_table(pending, npending, b.r.j, b.r.first_block);
+        if (rblocks < 0) return 1;
+        b.r.njobs = npending;
+    }
+    static_assert(sizeof(W16Batch) <= 4096, "kernel argument block");
+    hipLaunchKernelGGL(wgrad16_kernel, dim3(blocks + rblocks), dim3(256), 0, (hipStream_t)stream, b);
     return 0;
 }

@@ -326,7 +326,7 @@ class _LinearPair(Function):
             wg[i].dbias, wg[i].workspace, wg[i].ws_bytes = (db.data_ptr() if has_b else None), ws.data_ptr(), nbytes
             wg[i].rows_per_sample, wg[i].M, wg[i].N, wg[i].K, wg[i].precision = 1, M, N, K, precision()
             grads += [dw, db]
-        call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 2, ctypes.cast(jobs, ctypes.c_void_p), st)
+        call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 2, ctypes.cast(jobs, ctypes.c_void_p), None, 0, st)
         _reduce_jobs(jobs, keep, ctx.leaf)
         return (dx,) + tuple(grads)
 
@@ -665,13 +665,14 @@ class _CSWinBlock(Function):
         defer_wgrad(3, dqkv, h1, None, dwqkv, dbqkv, 4, 3 * C, C, io=3)  # dy = dqkv and x = h1 are stored as bf16
         wjobs = (ReduceJob * 4)()
         dh1 = datt                                                     # reuse again
+        pend, npend = take_pending_reductions()              # the previous blocks' slab reductions ride at the end of this grid
+        pend = ctypes.cast(pend, ctypes.c_void_p) if npend else None
         if precision() == 0:
-            # fp32: the qkv data gradient rides in the weight-gradient batch's launch (both only wait for dqkv)
-            pend, npend = take_pending_reductions()          # the previous blocks' slab reductions ride at the end of this grid
+            # fp32: the qkv data gradient rides in the weight-gradient batch's launch as well (both only wait for dqkv)
             call("cswin_linear_bwd_tail", ptr(dqkv), pq, ptr(dh1), M, 3 * C, C, ctypes.cast(wg, ctypes.c_void_p), 4,
-                 ctypes.cast(wjobs, ctypes.c_void_p), ctypes.cast(pend, ctypes.c_void_p) if npend else None, npend, st)
+                 ctypes.cast(wjobs, ctypes.c_void_p), pend, npend, st)
         else:
-            call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(wjobs, ctypes.c_void_p), st)
+            call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(wjobs, ctypes.c_void_p), pend, npend, st)
             call("cswin_linear_bwd_data", ptr(dqkv), pq, ptr(dh1), None, 0, None, None, 1, None, M, 3 * C, C, precision(), (1 if s16 else 0) | fq, st)
         for slot, ji in enumerate((0, 1, 3, 4)):
             jobs[ji] = wjobs[slot]

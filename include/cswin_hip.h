@@ -156,14 +156,17 @@ typedef struct cswin_wgrad_desc {
     int io_bf16;             /* precision 1 only: bit 0 = dy is stored as bf16, bit 1 = x is stored as bf16 */
 } cswin_wgrad_desc;
 /* Up to 4 independent weight gradients (the four nn.Linear of a CSWinBlock, cswin_unet.py:125,134,17-19) in ONE launch;
- * deferred[0..n) receive their slab reductions (required: run them with cswin_rows_sum_multi). */
-int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* problems, int n, cswin_reduce_job* deferred, void* stream);
+ * deferred[0..n) receive their slab reductions (required: run them with cswin_rows_sum_multi, or hand them to a later call as
+ * `pending`).  pending[0..npending), npending <= 16 (may be NULL / 0): reductions left pending by EARLIER calls; they are run by
+ * this launch's last workgroups -- memory-bound work beside matrix-pipe-bound work instead of a launch of its own -- or, where the
+ * batch does not go out as one launch, by a cswin_rows_sum_multi launch; either way they must not be run again. */
+int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* problems, int n, cswin_reduce_job* deferred, const cswin_reduce_job* pending,
+                                  int npending, void* stream);
 /* The tail of a CSWinBlock's backward (cswin_unet.py:171 / :125 backward): dx (M, K) = dy (M, N) @ w (N, K) -- the qkv Linear's data
  * gradient, plain fp32 operands -- together with the block's weight gradients (`problems`, `deferred` exactly as above).  Both
  * only wait for dqkv and neither needs the other: in fp32 with 16-B aligned operands they share ONE launch, otherwise the data
  * gradient is launched first and the batch follows; the results are those of cswin_linear_bwd_data + cswin_linear_bwd_weight_batch.
- * pending[0..npending), npending <= 16: reductions left pending by EARLIER calls (not this call's `deferred`): they are run by
- * this launch's last workgroups (or by a cswin_rows_sum_multi launch on the two-launch path) and must not be run again. */
+ * pending / npending as for cswin_linear_bwd_weight_batch. */
 int cswin_linear_bwd_tail(const float* dy, const float* w, float* dx, int M, int N, int K, const cswin_wgrad_desc* problems, int n,
                           cswin_reduce_job* deferred, const cswin_reduce_job* pending, int npending, void* stream);
 /* jobs: host array of 1..48 pending reductions (the workspaces they point into must still be alive) */

@@ -151,7 +151,7 @@ def test_linear_weight_gradient_batch(shapes):
         if scale is None:                                  # M not divisible by 3: build the per-row scale explicitly
             scale = np.array([rs[min(m // rps, 2)] for m in range(M)], np.float32)[:, None]
         refs.append((dw, db, (torch.from_numpy(dy * scale).T @ torch.from_numpy(x)), torch.from_numpy(dy * scale).sum(0)))
-    call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), n, ctypes.cast(jobs, ctypes.c_void_p), stream())
+    call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), n, ctypes.cast(jobs, ctypes.c_void_p), None, 0, stream())
     call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), n, stream())
     for i, (dw, db, dw_ref, db_ref) in enumerate(refs):
         rel_err(dw, dw_ref, f"wgrad_batch.{i}.dw")
@@ -203,7 +203,7 @@ def test_block_tail_launch_matches_the_two_launches(M, C):
                  ctypes.cast(jobs, ctypes.c_void_p), ctypes.cast(pend, ctypes.c_void_p), len(pend), stream())
         else:
             call("cswin_linear_bwd_data", ptr(dqkv), ptr(wq), ptr(dx), None, 0, None, None, 1, None, M, 3 * C, C, 0, 0, stream())
-            call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(jobs, ctypes.c_void_p), stream())
+            call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(jobs, ctypes.c_void_p), None, 0, stream())
             call("cswin_rows_sum_multi", ctypes.cast(pend, ctypes.c_void_p), 3, stream())
         call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), 4, stream())
         torch.cuda.synchronize()
@@ -219,6 +219,50 @@ def test_block_tail_launch_matches_the_two_launches(M, C):
     assert _rel_l2(dx1, dx0) < 1e-6, _rel_l2(dx1, dx0)
     rel_err(dx1, (dqkv.double() @ wq.double()).float().cpu(), f"tail.dx.{M}x{C}")
     for a, b in zip(o1, o0):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_weight_gradient_batch_carries_pending_reductions(prec):
+    """`pending` of cswin_linear_bwd_weight_batch: reductions left by earlier launches run as the last workgroups of this launch's
+    grid (fp32: gemm_block_tail_kernel without a data gradient; bf16 operands: wgrad16_kernel).  Same weight gradients as without
+    riders, and the riders' outputs equal the column sums of their slabs."""
+    import ctypes
+    from cswin_unet_amd._lib import ReduceJob, WgradDesc, call, lib, stream
+    M = 4704
+    shapes = [(256, 1024), (768, 256)]
+    dys = [T(det_normal(f"pend.dy{i}", (M, n_))) for i, (n_, k_) in enumerate(shapes)]
+    xs = [T(det_normal(f"pend.x{i}", (M, k_))) for i, (n_, k_) in enumerate(shapes)]
+
+    def run(with_pending):
+        wg, jobs, keep, outs = (WgradDesc * 2)(), (ReduceJob * 2)(), [], []
+        for i, (n_, k_) in enumerate(shapes):
+            dw, db = torch.empty(n_, k_, device=DEV), torch.empty(n_, device=DEV)
+            nbytes = lib().cswin_linear_bwd_weight_workspace(M, n_, k_)
+            ws = torch.empty(nbytes // 4 + 4, device=DEV)
+            keep.append(ws)
+            wg[i].dy, wg[i].x, wg[i].dw, wg[i].dbias = dys[i].data_ptr(), xs[i].data_ptr(), dw.data_ptr(), db.data_ptr()
+            wg[i].workspace, wg[i].ws_bytes, wg[i].rows_per_sample, wg[i].M, wg[i].N, wg[i].K, wg[i].precision = ws.data_ptr(), nbytes, 1, M, n_, k_, prec
+            outs += [dw, db]
+        pend, pouts = (ReduceJob * 3)(), []
+        for k, (rows, n, nf) in enumerate(((9, 8192, 8192), (200, 512, 256), (3, 50, 50))):
+            part, o1 = T(det_normal(f"pend.part{k}", (rows, n))), torch.full((nf,), float("nan"), device=DEV)
+            o2 = torch.full((n - nf,), float("nan"), device=DEV) if n > nf else None
+            pend[k].part, pend[k].out, pend[k].out2 = part.data_ptr(), o1.data_ptr(), (o2.data_ptr() if o2 is not None else None)
+            pend[k].n_first, pend[k].n, pend[k].stride, pend[k].rows = nf, n, n, rows
+            keep.append(part)
+            pouts.append((part, o1, o2, nf))
+        call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 2, ctypes.cast(jobs, ctypes.c_void_p),
+             ctypes.cast(pend, ctypes.c_void_p) if with_pending else None, 3 if with_pending else 0, stream())
+        call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), 2, stream())
+        torch.cuda.synchronize()
+        if with_pending:
+            for part, o1, o2, nf in pouts:
+                ref = part.double().sum(0)
+                assert _rel_l2(o1, ref[:nf]) < 1e-6 and (o2 is None or _rel_l2(o2, ref[nf:]) < 1e-6)
+        return outs
+
+    for a, b in zip(run(True), run(False)):
         assert torch.equal(a, b)
 
 
@@ -997,7 +1041,7 @@ def test_linear_bf16_storage_flags_bit_exact(M, Nn, K):
         wg[0].dy, wg[0].x, wg[0].row_scale = dyt.data_ptr(), xt.data_ptr(), (rs.data_ptr() if with_rs else None)
         wg[0].dw, wg[0].dbias, wg[0].workspace, wg[0].ws_bytes = dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nbytes
         wg[0].rows_per_sample, wg[0].M, wg[0].N, wg[0].K, wg[0].precision, wg[0].io_bf16 = rps, M, Nn, K, 1, io
-        call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 1, ctypes.cast(jobs, ctypes.c_void_p), stream())
+        call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 1, ctypes.cast(jobs, ctypes.c_void_p), None, 0, stream())
         call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), 1, stream())
         torch.cuda.synchronize()
         return dw, db
@@ -1771,7 +1815,7 @@ def test_linear_weight_gradient_batch_bf16(bf16_matmul, shapes):
         xt = torch.from_numpy(x)
         r16 = lambda t: t.to(torch.bfloat16).to(torch.float64)
         refs.append((dw, db, (r16(dys).T @ r16(xt)).float(), (dys.double().T @ xt.double()).float(), dys.double().sum(0).float()))
-    call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), n, ctypes.cast(jobs, ctypes.c_void_p), stream())
+    call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), n, ctypes.cast(jobs, ctypes.c_void_p), None, 0, stream())
     call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), n, stream())
     for i, (dw, db, ref16, ref32, db_ref) in enumerate(refs):
         got = dw.cpu()

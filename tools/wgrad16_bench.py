@@ -24,7 +24,7 @@ for si, (L, C, cnt) in enumerate([(3136, 64, 2), (784, 128, 4), (196, 256, 18), 
         wg[i].workspace, wg[i].ws_bytes, wg[i].rows_per_sample, wg[i].M, wg[i].N, wg[i].K = ws.data_ptr(), nbytes, 1, M, N, K
         wg[i].precision = 1 if os.environ.get("MATMUL", "bf16") == "bf16" else 0
     def run():
-        call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(jobs, ctypes.c_void_p), stream())
+        call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(jobs, ctypes.c_void_p), None, 0, stream())
         call("cswin_rows_sum_multi", ctypes.cast(jobs, ctypes.c_void_p), 4, stream())
     t = timed(run)
     fl = sum(2.0 * M * N * K for N, K in shapes)

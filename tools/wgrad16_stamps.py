@@ -24,7 +24,7 @@ for i, (N, K) in enumerate(shapes):
 st = torch.zeros(65536, 8, dtype=torch.int64, device="cuda")
 h = lib(); h.cswin_debug_set_stamps.argtypes = [ctypes.c_void_p]
 def run():
-    call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(jobs, ctypes.c_void_p), stream())
+    call("cswin_linear_bwd_weight_batch", ctypes.cast(wg, ctypes.c_void_p), 4, ctypes.cast(jobs, ctypes.c_void_p), None, 0, stream())
 for _ in range(3): run()
 torch.cuda.synchronize()
 h.cswin_debug_set_stamps(ctypes.c_void_p(st.data_ptr()))
