@@ -846,9 +846,10 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
 int cswin_rows_sum_multi(const cswin_reduce_job* jobs, int njobs, void* stream);
 }  // extern "C"
 namespace {
-// a plain fp32 data gradient dx[M,K] = dy[M,N] @ w[N,K] that may ride in the weight-gradient batch's launch (cswin_linear_bwd_tail)
-struct DgradRider { const float* dy; const float* w; float* dx; int M, N, K; const cswin_reduce_job* jobs; int njobs; };
-int wgrad_batch_impl(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferred, const DgradRider* rider, void* stream);
+// what may ride at the end of the weight-gradient batch's grid: a plain fp32 data gradient dx[M,K] = dy[M,N] @ w[N,K] (dy == NULL:
+// none; cswin_linear_bwd_tail) and reductions left pending by earlier launches
+struct TailExtras { const float* dy; const float* w; float* dx; int M, N, K; const cswin_reduce_job* jobs; int njobs; };
+int wgrad_batch_impl(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferred, const TailExtras* extra, void* stream);
 }  // namespace
 extern "C" {
 
@@ -914,7 +915,7 @@ int cswin_linear_bwd_weight_batch(const cswin_wgrad_desc* d, int n, cswin_reduce
                                   void* stream) {
     CSWIN_REQUIRE(npending >= 0 && npending <= CSWIN_TAIL_RIDER_JOBS && (npending == 0 || pending), CSWIN_ERR_SHAPE,
                   "linear_bwd_weight_batch: 0..%d pending reductions", CSWIN_TAIL_RIDER_JOBS);
-    DgradRider r = {nullptr, nullptr, nullptr, 0, 0, 0, pending, npending};
+    TailExtras r = {nullptr, nullptr, nullptr, 0, 0, 0, pending, npending};
     return wgrad_batch_impl(d, n, deferred, npending > 0 ? &r : nullptr, stream);
 }
 
@@ -926,13 +927,13 @@ int cswin_linear_bwd_tail(const float* dy, const float* w, float* dx, int M, int
     CSWIN_REQUIRE(dy && w && dx && M > 0 && N > 0 && K > 0, CSWIN_ERR_SHAPE, "linear_bwd_tail: bad data-gradient arguments");
     CSWIN_REQUIRE(npending >= 0 && npending <= CSWIN_TAIL_RIDER_JOBS && (npending == 0 || pending), CSWIN_ERR_SHAPE,
                   "linear_bwd_tail: 0..%d pending reductions", CSWIN_TAIL_RIDER_JOBS);
-    DgradRider r = {dy, w, dx, M, N, K, pending, npending};
+    TailExtras r = {dy, w, dx, M, N, K, pending, npending};
     return wgrad_batch_impl(d, n, deferred, &r, stream);
 }
 
 }  // extern "C"
 namespace {
-int wgrad_batch_impl(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferred, const DgradRider* rider, void* stream) {
+int wgrad_batch_impl(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferred, const TailExtras* extra, void* stream) {
     CSWIN_REQUIRE(d && deferred && n >= 1 && n <= WGRAD_BATCH, CSWIN_ERR_SHAPE, "linear_bwd_weight_batch: 1..%d problems and their deferred slots", WGRAD_BATCH);
     bool fast = true;
     const int precision = d[0].precision;
@@ -946,20 +947,20 @@ int wgrad_batch_impl(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferre
         CSWIN_REQUIRE(d[i].workspace && d[i].ws_bytes >= need, CSWIN_ERR_WORKSPACE, "linear_bwd_weight_batch: workspace %zu < %zu", d[i].ws_bytes, need);
         fast = fast && d[i].N % 4 == 0 && d[i].K % 4 == 0 && aligned16(d[i].dy) && aligned16(d[i].x) && aligned16(d[i].workspace);
     }
-    const bool has_dgrad = rider && rider->dy;
+    const bool has_dgrad = extra && extra->dy;
     const bool merge_on = cswin_tuning().gemm_tail_merge != 0;                                                  // tuning aid
-    const bool ride = rider && merge_on && fast && precision == 0 &&
-                      (!has_dgrad || (rider->N % 4 == 0 && rider->K % 4 == 0 && aligned16(rider->dy) && aligned16(rider->w) && aligned16(rider->dx)));
+    const bool ride = extra && merge_on && fast && precision == 0 &&
+                      (!has_dgrad || (extra->N % 4 == 0 && extra->K % 4 == 0 && aligned16(extra->dy) && aligned16(extra->w) && aligned16(extra->dx)));
     const bool w16_path = fast && precision == 1 && (cswin_tuning().wgrad16_on || d[0].io_bf16 || (n > 1 && d[1].io_bf16) || (n > 2 && d[2].io_bf16) || (n > 3 && d[3].io_bf16));
-    const bool jobs_ride16 = rider && merge_on && w16_path && rider->njobs > 0;       // bf16 mode: the reductions ride in wgrad16's grid
-    if (rider && !ride) {                   // the data gradient (and the pending reductions) as launches of their own, then the batch as usual
+    const bool jobs_ride16 = extra && merge_on && w16_path && extra->njobs > 0;       // bf16 mode: the reductions ride in wgrad16's grid
+    if (extra && !ride) {                   // the data gradient (and the pending reductions) as launches of their own, then the batch as usual
         if (has_dgrad) {
-            int rc = cswin_linear_bwd_data(rider->dy, rider->w, rider->dx, nullptr, 0, nullptr, nullptr, 1, nullptr, rider->M, rider->N,
-                                           rider->K, precision == 1 ? 1 : 0, 0, stream);
+            int rc = cswin_linear_bwd_data(extra->dy, extra->w, extra->dx, nullptr, 0, nullptr, nullptr, 1, nullptr, extra->M, extra->N,
+                                           extra->K, precision == 1 ? 1 : 0, 0, stream);
             if (rc) return rc;
         }
-        if (rider->njobs > 0 && !jobs_ride16) {
-            int rc = cswin_rows_sum_multi(rider->jobs, rider->njobs, stream);
+        if (extra->njobs > 0 && !jobs_ride16) {
+            int rc = cswin_rows_sum_multi(extra->jobs, extra->njobs, stream);
             if (rc) return rc;
         }
     }
@@ -995,7 +996,7 @@ int wgrad_batch_impl(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferre
             const long nk = (long)N * K;
             deferred[i] = cswin_reduce_job{(const float*)d[i].workspace, d[i].dw, d[i].dbias, nk, nk + (d[i].dbias ? N : 0), nk + N, splits[i], 0};
         }
-        CSWIN_REQUIRE(cswin_wgrad16_batch(d, n, splits, rps, jobs_ride16 ? rider->jobs : nullptr, jobs_ride16 ? rider->njobs : 0, stream, g_stamps) == 0,
+        CSWIN_REQUIRE(cswin_wgrad16_batch(d, n, splits, rps, jobs_ride16 ? extra->jobs : nullptr, jobs_ride16 ? extra->njobs : 0, stream, g_stamps) == 0,
                       CSWIN_ERR_SHAPE, "linear_bwd_weight_batch: bad pending reduction");
         CSWIN_LAUNCH_CHECK();
         return CSWIN_OK;
@@ -1046,21 +1047,21 @@ int wgrad_batch_impl(const cswin_wgrad_desc* d, int n, cswin_reduce_job* deferre
     if (ride) {
         BlockTail t = {};
         if (has_dgrad) {
-            Epilogue e = plain_epilogue(rider->dx, rider->K);
-            e.vec_store = epilogue_vec_ok(e, rider->K);
-            t.dA = PlainSrc{rider->dy, rider->N, rider->M, rider->N, nullptr, 1, 0};
-            t.dB = PlainSrc{rider->w, rider->K, rider->N, rider->K, nullptr, 1, 0};      // S(i = n (reduction), j = k)
+            Epilogue e = plain_epilogue(extra->dx, extra->K);
+            e.vec_store = epilogue_vec_ok(e, extra->K);
+            t.dA = PlainSrc{extra->dy, extra->N, extra->M, extra->N, nullptr, 1, 0};
+            t.dB = PlainSrc{extra->w, extra->K, extra->N, extra->K, nullptr, 1, 0};      // S(i = n (reduction), j = k)
             t.de = e;
-            t.dM = rider->M; t.dN = rider->K; t.dR = rider->N; t.drps = cdiv(rider->N, BKMAX) * BKMAX;
-            t.dtm = cdiv(rider->M, 64); t.dtn = cdiv(rider->K, 64);
+            t.dM = extra->M; t.dN = extra->K; t.dR = extra->N; t.drps = cdiv(extra->N, BKMAX) * BKMAX;
+            t.dtm = cdiv(extra->M, 64); t.dtn = cdiv(extra->K, 64);
             t.nd = t.dtm * t.dtn;
         }
         t.w = b;
         int rblocks = 0;
-        if (rider->njobs > 0) {
-            rblocks = fill_reduce_table(rider->jobs, rider->njobs, t.r.j, t.r.first_block);
+        if (extra->njobs > 0) {
+            rblocks = fill_reduce_table(extra->jobs, extra->njobs, t.r.j, t.r.first_block);
             CSWIN_REQUIRE(rblocks >= 0, CSWIN_ERR_SHAPE, "linear_bwd_tail: bad pending reduction");
-            t.r.njobs = rider->njobs;
+            t.r.njobs = extra->njobs;
         }
         static_assert(sizeof(BlockTail) <= 4096, "kernel argument block");
         hipLaunchKernelGGL(gemm_block_tail_kernel, dim3(blocks + t.nd + rblocks), dim3(512), 0, (hipStream_t)stream, t);
